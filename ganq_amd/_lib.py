@@ -1,0 +1,220 @@
+"""ctypes binding of libganq_hip.so (C-ABI declared in include/ganq_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If the shared object is
+missing, fails to load or lacks a symbol, importing a compute entry point raises
+``GanqHipError`` -- loudly, by design.
+
+Tensors are torch-owned; this layer only borrows ``data_ptr()`` for the duration of a call
+and passes ``torch.cuda.current_stream().cuda_stream`` (reference boundary: the tensors that
+``GANQ._perform_quantization_loop`` receives, gptqmodel/quantization/ganq.py:456).
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libganq_hip.so")
+CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
+
+FLAG_ALIAS_Q = 1
+
+_c_i64 = ctypes.c_int64
+_c_vp = ctypes.c_void_p
+_c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ganq_hip.h one to one
+SIGNATURES = {
+    "ganq_hip_version": (ctypes.c_int, []),
+    "ganq_hip_last_error": (ctypes.c_char_p, []),
+    "ganq_hip_selftest": (ctypes.c_int, [_c_vp]),
+    "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp]),
+    "ganq_kmeans_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
+    "ganq_kmeans_init": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ganq_solve_s_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
+    "ganq_solve_s": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_vp,
+                                    _c_sz, _c_vp]),
+    "ganq_matmul_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp]),
+    "ganq_update_t_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
+    "ganq_update_t": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, ctypes.c_double, _c_vp, _c_vp,
+                                     _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ganq_quad_loss_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
+    "ganq_quad_loss": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_sz,
+                                      _c_vp]),
+    "ganq_dequant_losses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp,
+                                           _c_vp]),
+    "ganq_run_layer_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
+    "ganq_run_layer": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_uint32, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
+                                      _c_vp]),
+    "ganq_lut_linear_fwd": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64,
+                                           ctypes.c_int, _c_vp, _c_vp]),
+    "ganq_pack_indices": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
+    "ganq_unpack_indices": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
+}
+
+
+class GanqHipError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(force: bool = False) -> str:
+    """Compile libganq_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j8"] + (["-B"] if force else [])
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise GanqHipError("building libganq_hip.so failed:\n" + proc.stdout[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library and bind every symbol the header declares."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise GanqHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                                   f"g.build()'` (or `make -C ganq_amd/csrc`). There is no CPU fallback.")
+            try:
+                handle = ctypes.CDLL(LIB_PATH)
+            except OSError as e:
+                raise GanqHipError(f"cannot load {LIB_PATH}: {e}") from e
+            for name, (res, args) in SIGNATURES.items():
+                try:
+                    fn = getattr(handle, name)
+                except AttributeError as e:
+                    raise GanqHipError(f"{LIB_PATH} does not export {name}") from e
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().ganq_hip_last_error()
+        raise GanqHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise GanqHipError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise GanqHipError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def selftest():
+    _check(lib().ganq_hip_selftest(_stream()), "ganq_hip_selftest")
+
+
+def solve_s(W, L, T, want_err=False):
+    """ganq.py:533-565.  W [m,n], L [n,n] lower, T [m,V] (fp32, cuda) -> Q uint8 [m,n] (, Err fp32 [m,n])."""
+    W, T = _dev_f32(W, "W"), _dev_f32(T, "T")
+    if not (L.is_cuda and L.dtype == torch.float32 and L.stride(1) == 1):
+        L = _dev_f32(L, "L")
+    m, n = W.shape
+    V = T.shape[1]
+    if L.shape != (n, n) or T.shape[0] != m:
+        raise GanqHipError(f"shape mismatch W{tuple(W.shape)} L{tuple(L.shape)} T{tuple(T.shape)}")
+    Q = torch.empty((m, n), dtype=torch.uint8, device=W.device)
+    Err = torch.empty((m, n), dtype=torch.float32, device=W.device) if want_err else None
+    ws = _workspace(lib().ganq_solve_s_workspace_bytes(m, n, V), W.device)
+    _check(lib().ganq_solve_s(W.data_ptr(), L.data_ptr(), L.stride(0), T.data_ptr(), m, n, V, Q.data_ptr(), _ptr(Err),
+                              ws.data_ptr(), ws.numel(), _stream()), "ganq_solve_s")
+    return (Q, Err) if want_err else Q
+
+
+def matmul_f32(A, B):
+    A, B = _dev_f32(A, "A"), _dev_f32(B, "B")
+    m, k = A.shape
+    if B.shape[0] != k:
+        raise GanqHipError(f"shape mismatch A{tuple(A.shape)} B{tuple(B.shape)}")
+    n = B.shape[1]
+    C = torch.empty((m, n), dtype=torch.float32, device=A.device)
+    _check(lib().ganq_matmul_f32(A.data_ptr(), B.data_ptr(), m, k, n, C.data_ptr(), _stream()), "ganq_matmul_f32")
+    return C
+
+
+def update_t(WH, H, Q, V, rcond=-1.0, want_ab=False):
+    """ganq.py:570-591 (gelsd branch).  -> T [m,V] (, A [m,V,V], b [m,V])."""
+    WH, H = _dev_f32(WH, "WH"), _dev_f32(H, "H")
+    if Q.dtype != torch.uint8 or not Q.is_cuda:
+        raise GanqHipError("Q must be a uint8 cuda tensor")
+    Q = Q.contiguous()
+    m, n = WH.shape
+    T = torch.empty((m, V), dtype=torch.float32, device=WH.device)
+    A = torch.empty((m, V, V), dtype=torch.float32, device=WH.device) if want_ab else None
+    b = torch.empty((m, V), dtype=torch.float32, device=WH.device) if want_ab else None
+    ws = _workspace(lib().ganq_update_t_workspace_bytes(m, n, V), WH.device)
+    _check(lib().ganq_update_t(WH.data_ptr(), H.data_ptr(), Q.data_ptr(), m, n, V, float(rcond), T.data_ptr(), _ptr(A),
+                               _ptr(b), ws.data_ptr(), ws.numel(), _stream()), "ganq_update_t")
+    return (T, A, b) if want_ab else T
+
+
+def quad_loss(W, H, T, Q):
+    """ganq.py:392-395 on Wq = T.gather(1,Q).  Returns a 0-dim float64 cuda tensor (no sync)."""
+    W, H, T = _dev_f32(W, "W"), _dev_f32(H, "H"), _dev_f32(T, "T")
+    Q = Q.contiguous()
+    m, n = W.shape
+    out = torch.empty((), dtype=torch.float64, device=W.device)
+    ws = _workspace(lib().ganq_quad_loss_workspace_bytes(m, n, T.shape[1]), W.device)
+    _check(lib().ganq_quad_loss(W.data_ptr(), H.data_ptr(), T.data_ptr(), Q.data_ptr(), m, n, T.shape[1],
+                                out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ganq_quad_loss")
+    return out
+
+
+def dequant_losses(W, T, Q, hinv_diag, want_losses=True):
+    """ganq.py:633-638.  -> (Wq [m,n], Losses [m,n] or None)."""
+    W, T = _dev_f32(W, "W"), _dev_f32(T, "T")
+    Q = Q.contiguous()
+    m, n = W.shape
+    Wq = torch.empty((m, n), dtype=torch.float32, device=W.device)
+    Lo = torch.empty((m, n), dtype=torch.float32, device=W.device) if want_losses else None
+    hd = _dev_f32(hinv_diag, "hinv_diag") if want_losses else None
+    _check(lib().ganq_dequant_losses(W.data_ptr(), T.data_ptr(), Q.data_ptr(), _ptr(hd), m, n, T.shape[1],
+                                     Wq.data_ptr(), _ptr(Lo), _stream()), "ganq_dequant_losses")
+    return Wq, Lo
+
+
+def run_layer_workspace(m, n, V, device):
+    return _workspace(lib().ganq_run_layer_workspace_bytes(m, n, V), device)
+
+
+def run_layer(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None):
+    """ganq.py:516-634.  -> (T_best [m,V], Q uint8 [m,n], dists float64 [K], best_k int32 0-dim); all on the GPU."""
+    W, H, T0 = _dev_f32(W, "W"), _dev_f32(H, "H"), _dev_f32(T0, "T0")
+    if not (L.is_cuda and L.dtype == torch.float32 and L.stride(1) == 1):
+        L = _dev_f32(L, "L")
+    m, n = W.shape
+    V = T0.shape[1]
+    if H.shape != (n, n) or L.shape != (n, n) or T0.shape[0] != m:
+        raise GanqHipError(f"shape mismatch W{tuple(W.shape)} H{tuple(H.shape)} L{tuple(L.shape)} T0{tuple(T0.shape)}")
+    T = torch.empty((m, V), dtype=torch.float32, device=W.device)
+    Q = torch.empty((m, n), dtype=torch.uint8, device=W.device)
+    dists = torch.zeros((max(K, 1),), dtype=torch.float64, device=W.device)
+    best_k = torch.full((), -1, dtype=torch.int32, device=W.device)
+    ws = workspace if workspace is not None else run_layer_workspace(m, n, V, W.device)
+    _check(lib().ganq_run_layer(W.data_ptr(), H.data_ptr(), L.data_ptr(), L.stride(0), T0.data_ptr(), m, n, V, int(K),
+                                FLAG_ALIAS_Q if alias_q else 0, float(rcond), T.data_ptr(), Q.data_ptr(),
+                                dists.data_ptr(), best_k.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+           "ganq_run_layer")
+    return T, Q, dists[:K], best_k

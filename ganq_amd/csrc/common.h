@@ -1,0 +1,50 @@
+// Shared helpers for libganq_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/ganq_hip.h"
+
+namespace ganq {
+
+// thread-local error text returned by ganq_hip_last_error()
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+#define GANQ_HIP_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return ::ganq::fail(-100, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define GANQ_LAUNCH_CHECK() GANQ_HIP_CHECK(hipGetLastError())
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// carve aligned sub-buffers out of a caller-provided workspace
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t used() const { return align_up(off, 256); }
+};
+
+// 1 if v_mfma_f32_16x16x4_f32 accumulates k = 0,1,2,3 in that order (fma(a3,b3,fma(a2,b2,fma(a1,b1,fma(a0,b0,c))))),
+// 0 if k = 3,2,1,0; negative until ganq_hip_selftest has run / on failure.
+int mfma_k_ascending();
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+}  // namespace ganq

@@ -1,0 +1,150 @@
+// The whole alternating optimisation of one layer (reference ganq.py:516-634):
+//   K x ( S-solve -> T-update -> loss ) with best-of-K selection, enqueued on one stream with no host
+//   synchronisation: the "is this iteration the best so far" decision and the conditional copies run on
+//   the device.
+#include <cmath>
+
+#include "common.h"
+
+namespace ganq {
+
+__global__ void best_init_kernel(double* best, int32_t* best_k, int32_t* flag) {
+    *best = INFINITY;
+    *best_k = -1;
+    *flag = 0;
+}
+
+// ganq.py:625-626   if curr_dist < best: best = (curr_dist, T, Q)   (strict <, NaN never wins)
+__global__ void best_select_kernel(const double* dist, int k, double* best, int32_t* best_k, int32_t* flag) {
+    const double d = *dist;
+    if (d < *best) {
+        *best = d;
+        *best_k = k;
+        *flag = 1;
+    } else {
+        *flag = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_if_kernel(const int32_t* __restrict__ flag, const uint32_t* __restrict__ src,
+                                                      uint32_t* __restrict__ dst, int64_t words,
+                                                      const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail,
+                                                      int tail) {
+    if (*flag == 0) return;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+// "no iteration won" (all distances NaN): hand back the last codebook instead of leaving T_best unwritten
+__global__ __launch_bounds__(256) void copy_if_none_kernel(const int32_t* __restrict__ best_k, const float* __restrict__ src,
+                                                           float* __restrict__ dst, int64_t count) {
+    if (*best_k >= 0) return;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) dst[i] = src[i];
+}
+
+static int launch_copy_if(const int32_t* flag, const void* src, void* dst, size_t bytes, hipStream_t stream) {
+    const int64_t words = (int64_t)(bytes / 4);
+    const int tail = (int)(bytes % 4);
+    const int blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (words + 255) / 256));
+    hipLaunchKernelGGL(copy_if_kernel, dim3(blocks), dim3(256), 0, stream, flag, static_cast<const uint32_t*>(src),
+                       static_cast<uint32_t*>(dst), words, static_cast<const uint8_t*>(src) + words * 4,
+                       static_cast<uint8_t*>(dst) + words * 4, tail);
+    GANQ_LAUNCH_CHECK();
+    return 0;
+}
+
+struct RunLayout {
+    size_t off_wh, off_t0, off_t1, off_q, off_solve, off_upd, off_loss, off_best, off_flag, total;
+    size_t solve_bytes, upd_bytes, loss_bytes;
+};
+
+static RunLayout run_layout(int64_t m, int64_t n, int V) {
+    RunLayout lo;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    lo.solve_bytes = ganq_solve_s_workspace_bytes(m, n, V);
+    lo.upd_bytes = ganq_update_t_workspace_bytes(m, n, V);
+    lo.loss_bytes = ganq_quad_loss_workspace_bytes(m, n, V);
+    lo.off_wh = take((size_t)m * n * sizeof(float));
+    lo.off_t0 = take((size_t)m * V * sizeof(float));
+    lo.off_t1 = take((size_t)m * V * sizeof(float));
+    lo.off_q = take((size_t)m * n);
+    lo.off_solve = take(lo.solve_bytes);
+    lo.off_upd = take(lo.upd_bytes);
+    lo.off_loss = take(lo.loss_bytes);
+    lo.off_best = take(sizeof(double));
+    lo.off_flag = take(sizeof(int32_t));
+    lo.total = off;
+    return lo;
+}
+
+}  // namespace ganq
+
+using namespace ganq;
+
+extern "C" size_t ganq_run_layer_workspace_bytes(int64_t m, int64_t n, int V) {
+    if (m <= 0 || n <= 0) return 0;
+    return run_layout(m, n, V).total;
+}
+
+extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, int64_t ldl, const float* T0, int64_t m,
+                              int64_t n, int V, int K, uint32_t flags, double rcond, float* T_best, uint8_t* Q_out,
+                              double* dists, int32_t* best_k, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (m < 0 || n < 0 || K < 0) return fail(-1, "ganq_run_layer: negative shape / K");
+    if (m == 0 || n == 0 || K == 0) return 0;
+    if (V < 2 || V > 16) return fail(-2, "ganq_run_layer: V=%d not supported (bits 2..4 are implemented)", V);
+    if (!W || !H || !L || !T0 || !T_best || !Q_out || !dists || !best_k) return fail(-3, "ganq_run_layer: null pointer");
+    const RunLayout lo = run_layout(m, n, V);
+    if (!workspace || workspace_bytes < lo.total)
+        return fail(-4, "ganq_run_layer: workspace %zu B < required %zu B", workspace_bytes, lo.total);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = ganq_hip_selftest(stream_);
+    if (rc) return rc;
+    char* ws = static_cast<char*>(workspace);
+    float* WH = reinterpret_cast<float*>(ws + lo.off_wh);
+    float* Tc = reinterpret_cast<float*>(ws + lo.off_t0);
+    float* Tn = reinterpret_cast<float*>(ws + lo.off_t1);
+    uint8_t* Qc = reinterpret_cast<uint8_t*>(ws + lo.off_q);
+    double* best = reinterpret_cast<double*>(ws + lo.off_best);
+    int32_t* flag = reinterpret_cast<int32_t*>(ws + lo.off_flag);
+    const bool alias = (flags & GANQ_FLAG_ALIAS_Q) != 0;
+    // with the reference's aliasing the returned indices are simply those of the last iteration
+    uint8_t* Qwork = alias ? Q_out : Qc;
+
+    rc = ganq_matmul_f32(W, H, m, n, n, WH, stream_);  // W @ H is iteration-invariant (ganq.py:590)
+    if (rc) return rc;
+    GANQ_HIP_CHECK(hipMemcpyAsync(Tc, T0, (size_t)m * V * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(best_init_kernel, dim3(1), dim3(1), 0, stream, best, best_k, flag);
+    GANQ_LAUNCH_CHECK();
+
+    for (int k = 0; k < K; ++k) {
+        rc = ganq_solve_s(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, lo.solve_bytes, stream_);
+        if (rc) return rc;
+        rc = ganq_update_t(WH, H, Qwork, m, n, V, rcond, Tn, nullptr, nullptr, ws + lo.off_upd, lo.upd_bytes, stream_);
+        if (rc) return rc;
+        std::swap(Tc, Tn);
+        rc = ganq_quad_loss(W, H, Tc, Qwork, m, n, V, dists + k, ws + lo.off_loss, lo.loss_bytes, stream_);
+        if (rc) return rc;
+        hipLaunchKernelGGL(best_select_kernel, dim3(1), dim3(1), 0, stream, dists + k, k, best, best_k, flag);
+        GANQ_LAUNCH_CHECK();
+        rc = launch_copy_if(flag, Tc, T_best, (size_t)m * V * sizeof(float), stream);
+        if (rc) return rc;
+        if (!alias) {
+            if (k == 0) {  // defined contents even if no iteration ever wins (all distances NaN)
+                GANQ_HIP_CHECK(hipMemcpyAsync(Q_out, Qwork, (size_t)m * n, hipMemcpyDeviceToDevice, stream));
+            } else {
+                rc = launch_copy_if(flag, Qwork, Q_out, (size_t)m * n, stream);
+                if (rc) return rc;
+            }
+        }
+    }
+    hipLaunchKernelGGL(copy_if_none_kernel, dim3(64), dim3(256), 0, stream, best_k, Tc, T_best, (int64_t)m * V);
+    GANQ_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,113 @@
+/*
+ * ganq_hip.h -- C-ABI of libganq_hip.so: the MI355X (gfx950) implementation of GANQ's per-layer
+ * alternating optimisation and of the LUT-dequant linear forward.
+ *
+ * This is the drop-in boundary for ONE path of smpanaro/ganq (a GPTQModel fork): what
+ * `GANQ._perform_quantization_loop` (gptqmodel/quantization/ganq.py:456-646), the Hessian
+ * accumulation it inherits (gptqmodel/quantization/gptq.py:88-131) and
+ * `FakeQuantLinear.forward` (gptqmodel/nn_modules/qlinear/fake.py:88-89) compute.  The
+ * reference has no FFI for this path (its only native code is Metal source embedded in
+ * ganq.py:39-328); each entry point below names the reference lines it replaces, and
+ * INTEGRATION.md shows the ctypes binding a maintainer would add to ganq.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch tensor.data_ptr()) unless marked host;
+ *     buffers are borrowed for the duration of the call only, outputs are caller-allocated;
+ *   - matrices are row-major and contiguous unless a leading dimension is given;
+ *   - m = out_features (rows of W), n = in_features (columns), V = 2^bits codebook entries;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     calls are asynchronous on that stream and re-entrant per stream;
+ *   - return value 0 = ok; <0 = error, text via ganq_hip_last_error() (thread-local).
+ *   - Q is one uint8 per index ([m,n]); bits in {2,3,4} (V <= 16) are implemented.
+ */
+#ifndef GANQ_HIP_H
+#define GANQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANQ_HIP_ABI_VERSION 1
+
+/* flags for ganq_run_layer */
+#define GANQ_FLAG_ALIAS_Q 1u /* reference torch-branch behaviour: indices of the LAST iteration are returned with \
+                                the codebook of the BEST one (ganq.py:487,550,625-626) */
+
+int ganq_hip_version(void);
+const char* ganq_hip_last_error(void);
+
+/* Device self-test: determines the accumulation order of v_mfma_f32_16x16x4_f32 on this GPU and
+ * checks it against an fmaf chain (the S-solve's bit-exactness contract depends on it).
+ * Returns 0 and caches the result; the compute entry points call it lazily. */
+int ganq_hip_selftest(void* stream);
+
+/* ---- a1: Hessian accumulation (gptq.py:96-131 process_batch) --------------------------------
+ * One calibration batch: X [rows, n] fp16 or bf16 (dtype: 0 = fp16, 1 = bf16), `batch` = number
+ * of sequences in it (gptq.py:104), nsamples_before = sequences accumulated so far.
+ *     H <- H * N/(N+batch) + (2/(N+batch)) * X^T X          H [n,n] fp32, updated in place       */
+int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
+                       int64_t batch, void* stream);
+
+/* ---- a3: codebook initialisation (ganq.py:423-438, kmeans_fit :27-30) -----------------------
+ * Optimal weighted 1-D k-means per row; col_weight [n] fp64 (caller passes diag(Hinv)^-4).
+ * T0 [m,V] fp32 ascending per row.  workspace: ganq_kmeans_workspace_bytes().               */
+size_t ganq_kmeans_workspace_bytes(int64_t m, int64_t n, int V);
+int ganq_kmeans_init(const float* W, const double* col_weight, int64_t m, int64_t n, int V, float* T0,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a4/a5: S-solve (ganq.py:533-565 torch branch == Metal kernel compute_s :39-270) --------
+ * W [m,n], L [n,n] lower-triangular with leading dimension ldl, T [m,V].
+ * Q_out [m,n] uint8.  Err_out [m,n] fp32 (W - T[Q]; the Metal kernel's `Werr`) or NULL.
+ * workspace: ganq_solve_s_workspace_bytes().                                                  */
+size_t ganq_solve_s_workspace_bytes(int64_t m, int64_t n, int V);
+int ganq_solve_s(const float* W, const float* L, int64_t ldl, const float* T, int64_t m, int64_t n, int V,
+                 uint8_t* Q_out, float* Err_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- dense fp32 product C[m,n] = A[m,k] @ B[k,n] on the fp32 matrix cores (W@H, ganq.py:590) */
+int ganq_matmul_f32(const float* A, const float* B, int64_t m, int64_t k, int64_t n, float* C, void* stream);
+
+/* ---- a6: T-update (ganq.py:570-591, CPU/gelsd branch) ---------------------------------------
+ * WH = W @ H [m,n], H = Xxt_damped [n,n], Q [m,n].  T_out [m,V] = min-norm lstsq(S H S^T, S (WH)^T)
+ * with cut-off rcond (<0: eps_fp32 * V, the torch default).  A_out [m,V,V] / b_out [m,V]: the
+ * normal-equation matrices (optional, may be NULL).                                            */
+size_t ganq_update_t_workspace_bytes(int64_t m, int64_t n, int V);
+int ganq_update_t(const float* WH, const float* H, const uint8_t* Q, int64_t m, int64_t n, int V, double rcond,
+                  float* T_out, float* A_out, float* b_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a7: loss (ganq.py:392-395 quad_loss_2 on Wq = T.gather(1,Q), :621-622) -----------------
+ * loss_out: one fp64 on the device.  workspace: ganq_quad_loss_workspace_bytes().             */
+size_t ganq_quad_loss_workspace_bytes(int64_t m, int64_t n, int V);
+int ganq_quad_loss(const float* W, const float* H, const float* T, const uint8_t* Q, int64_t m, int64_t n, int V,
+                   double* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a7: outputs (ganq.py:633-638): Wq = T.gather(1,Q); Losses = (W-Wq)^2 / diag(Hinv)^2 / 2 -
+ * Wq_out / Losses_out [m,n] fp32, either may be NULL.                                          */
+int ganq_dequant_losses(const float* W, const float* T, const uint8_t* Q, const float* hinv_diag, int64_t m,
+                        int64_t n, int V, float* Wq_out, float* Losses_out, void* stream);
+
+/* ---- the whole loop (ganq.py:516-634): K x (S-solve, T-update, loss) + best-of-K ------------
+ * Inputs as above plus T0 [m,V].  Outputs: T_best [m,V], Q_out [m,n], dists [K] fp64 (device),
+ * best_k (device int32).  No host synchronisation inside.                                      */
+size_t ganq_run_layer_workspace_bytes(int64_t m, int64_t n, int V);
+int ganq_run_layer(const float* W, const float* H, const float* L, int64_t ldl, const float* T0, int64_t m,
+                   int64_t n, int V, int K, uint32_t flags, double rcond, float* T_best, uint8_t* Q_out,
+                   double* dists, int32_t* best_k, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a9: LUT-dequant linear forward (replaces FakeQuantLinear.forward, fake.py:88-89) -------
+ * y[M,m] = x[M,n] @ dequant(qweight, lut)^T + bias.   dtype: 0 = fp16, 1 = bf16 (x, lut, bias, y).
+ * qweight: indices packed `bits` per index along the in_features dimension in the GPTQ int32
+ * layout qweight[n*bits/32, m] (qlinear/__init__.py:508-517); lut [m,V]; bias [m] or NULL.     */
+int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, const void* bias, int dtype,
+                        int64_t M, int64_t m, int64_t n, int bits, void* y, void* stream);
+
+/* pack Q [m,n] uint8 (original column order) into qweight [n*bits/32, m] int32, and back */
+int ganq_pack_indices(const uint8_t* Q, int64_t m, int64_t n, int bits, int32_t* qweight, void* stream);
+int ganq_unpack_indices(const int32_t* qweight, int64_t m, int64_t n, int bits, uint8_t* Q, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANQ_HIP_H */
