@@ -49,10 +49,17 @@ SIGNATURES = {
     "ganq_run_layer": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_uint32, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
                                       _c_vp]),
+    "ganq_lut_linear_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, ctypes.c_int]),
     "ganq_lut_linear_fwd": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64,
-                                           ctypes.c_int, _c_vp, _c_vp]),
+                                           ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ganq_lut_dequant": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
     "ganq_pack_indices": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
     "ganq_unpack_indices": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
+    "ganq_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "ganq_profile_reset": (ctypes.c_int, []),
+    "ganq_profile_num_kernels": (ctypes.c_int, []),
+    "ganq_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "ganq_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)]),
 }
 
 
@@ -218,3 +225,108 @@ def run_layer(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None):
                                 dists.data_ptr(), best_k.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
            "ganq_run_layer")
     return T, Q, dists[:K], best_k
+
+
+def profile_enable(on: bool = True):
+    lib().ganq_profile_reset()
+    lib().ganq_profile_enable(1 if on else 0)
+
+
+def profile_report():
+    """{kernel name: (total_ms, launches)} for everything recorded since profile_enable(); synchronises first."""
+    torch.cuda.synchronize()
+    out = {}
+    for kid in range(lib().ganq_profile_num_kernels()):
+        ms, cnt = ctypes.c_double(0.0), _c_i64(0)
+        _check(lib().ganq_profile_get(kid, ctypes.byref(ms), ctypes.byref(cnt)), "ganq_profile_get")
+        if cnt.value:
+            out[lib().ganq_profile_kernel_name(kid).decode()] = (ms.value, cnt.value)
+    return out
+
+
+_DTYPE_CODE = {torch.float16: 0, torch.bfloat16: 1}
+
+
+def _act_dtype(t, name):
+    if t.dtype not in _DTYPE_CODE:
+        raise GanqHipError(f"{name} must be float16 or bfloat16, got {t.dtype}")
+    if not t.is_cuda:
+        raise GanqHipError(f"{name} must live on the GPU; the HIP path has no CPU fallback")
+    return _DTYPE_CODE[t.dtype]
+
+
+def hessian_accum(H, X, nsamples_before: int, batch: int):
+    """gptq.py:96-131.  H [n,n] fp32 (updated in place), X [rows, n] fp16/bf16 (one calibration batch of
+    `batch` sequences, flattened)."""
+    if not (H.is_cuda and H.dtype == torch.float32 and H.is_contiguous()):
+        raise GanqHipError("H must be a contiguous float32 cuda tensor")
+    code = _act_dtype(X, "X")
+    X = X.contiguous()
+    rows, n = X.shape
+    if H.shape != (n, n):
+        raise GanqHipError(f"shape mismatch H{tuple(H.shape)} X{tuple(X.shape)}")
+    _check(lib().ganq_hessian_accum(H.data_ptr(), X.data_ptr(), code, rows, n, int(nsamples_before), int(batch),
+                                    _stream()), "ganq_hessian_accum")
+    return H
+
+
+def kmeans_init(W, col_weight, V: int):
+    """ganq.py:423-438.  W [m,n] fp32, col_weight [n] float64 (diag(Hinv)^-4) or None -> T0 [m,V] fp32."""
+    W = _dev_f32(W, "W")
+    m, n = W.shape
+    cw = None
+    if col_weight is not None:
+        cw = col_weight.to(device=W.device, dtype=torch.float64).contiguous()
+        if cw.shape != (n,):
+            raise GanqHipError("col_weight must have shape [n]")
+    T0 = torch.empty((m, V), dtype=torch.float32, device=W.device)
+    ws = _workspace(lib().ganq_kmeans_workspace_bytes(m, n, V), W.device)
+    _check(lib().ganq_kmeans_init(W.data_ptr(), _ptr(cw), m, n, V, T0.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+           "ganq_kmeans_init")
+    return T0
+
+
+def pack_indices(Q, bits: int):
+    """Q uint8 [m,n] (original column order) -> qweight int32 [n*bits/32, m] (GPTQ layout)."""
+    if Q.dtype != torch.uint8 or not Q.is_cuda:
+        raise GanqHipError("Q must be a uint8 cuda tensor")
+    Q = Q.contiguous()
+    m, n = Q.shape
+    qw = torch.empty((n * bits // 32, m), dtype=torch.int32, device=Q.device)
+    _check(lib().ganq_pack_indices(Q.data_ptr(), m, n, bits, qw.data_ptr(), _stream()), "ganq_pack_indices")
+    return qw
+
+
+def unpack_indices(qweight, n: int, bits: int):
+    if qweight.dtype != torch.int32 or not qweight.is_cuda:
+        raise GanqHipError("qweight must be an int32 cuda tensor")
+    qweight = qweight.contiguous()
+    m = qweight.shape[1]
+    Q = torch.empty((m, n), dtype=torch.uint8, device=qweight.device)
+    _check(lib().ganq_unpack_indices(qweight.data_ptr(), m, n, bits, Q.data_ptr(), _stream()), "ganq_unpack_indices")
+    return Q
+
+
+def lut_dequant(qweight, lut, n: int, bits: int):
+    code = _act_dtype(lut, "lut")
+    qweight, lut = qweight.contiguous(), lut.contiguous()
+    m = lut.shape[0]
+    Wq = torch.empty((m, n), dtype=lut.dtype, device=lut.device)
+    _check(lib().ganq_lut_dequant(qweight.data_ptr(), lut.data_ptr(), code, m, n, bits, Wq.data_ptr(), _stream()),
+           "ganq_lut_dequant")
+    return Wq
+
+
+def lut_linear(x, qweight, lut, bias, bits: int):
+    """x [M,n] (M <= 16) fp16/bf16, qweight int32 [n*bits/32, m], lut [m,V], bias [m] or None -> y [M,m]."""
+    code = _act_dtype(x, "x")
+    if lut.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype):
+        raise GanqHipError("x, lut and bias must share one dtype")
+    x, qweight, lut = x.contiguous(), qweight.contiguous(), lut.contiguous()
+    M, n = x.shape
+    m = lut.shape[0]
+    y = torch.empty((M, m), dtype=x.dtype, device=x.device)
+    ws = _workspace(lib().ganq_lut_linear_workspace_bytes(M, m, n, bits), x.device)
+    _check(lib().ganq_lut_linear_fwd(x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), code, M, m, n, bits,
+                                     y.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ganq_lut_linear_fwd")
+    return y

@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...);
 
 #define GANQ_LAUNCH_CHECK() GANQ_HIP_CHECK(hipGetLastError())
 
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // carve aligned sub-buffers out of a caller-provided workspace
 struct Carver {
@@ -43,6 +43,37 @@ struct Carver {
 // 1 if v_mfma_f32_16x16x4_f32 accumulates k = 0,1,2,3 in that order (fma(a3,b3,fma(a2,b2,fma(a1,b1,fma(a0,b0,c))))),
 // 0 if k = 3,2,1,0; negative until ganq_hip_selftest has run / on failure.
 int mfma_k_ascending();
+
+// ---- optional per-kernel timing (profile.hip) ----
+enum KernelId : int {
+    KID_SOLVE_S = 0,
+    KID_GEMM_F32,
+    KID_SORT_CODES,
+    KID_SHT_ACCUM,
+    KID_T_SOLVE,
+    KID_ERR,
+    KID_DOT,
+    KID_DEQUANT,
+    KID_HESSIAN,
+    KID_KMEANS,
+    KID_LUT_GEMV,
+    KID_LUT_GEMM,
+    KID_PACK,
+    KID_COUNT
+};
+bool profile_enabled();
+void profile_mark(int kid, hipStream_t stream, bool begin);
+struct ProfScope {
+    int kid;
+    hipStream_t stream;
+    bool on;
+    ProfScope(int k, hipStream_t s) : kid(k), stream(s), on(profile_enabled()) {
+        if (on) profile_mark(kid, stream, true);
+    }
+    ~ProfScope() {
+        if (on) profile_mark(kid, stream, false);
+    }
+};
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;

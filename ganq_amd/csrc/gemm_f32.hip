@@ -148,6 +148,7 @@ extern "C" int ganq_matmul_f32(const float* A, const float* B, int64_t m, int64_
     if (!A || !B || !C) return fail(-3, "ganq_matmul_f32: null pointer");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles = (int)(((m + GM - 1) / GM) * ((n + GN - 1) / GN));
+    ProfScope prof(KID_GEMM_F32, stream);
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, stream, A, B, C, (int)m, (int)n, (int)k);
     GANQ_LAUNCH_CHECK();
     return 0;

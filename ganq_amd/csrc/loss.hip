@@ -102,14 +102,19 @@ extern "C" int ganq_quad_loss(const float* W, const float* H, const float* T, co
     float* EH = reinterpret_cast<float*>(ws + mat);
     double* partial = reinterpret_cast<double*>(ws + 2 * mat);
     const int64_t total = m * n;
-    hipLaunchKernelGGL(err_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, stream, W, T, Q, total, (int)n, V,
-                       E);
+    {
+        ProfScope prof(KID_ERR, stream);
+        hipLaunchKernelGGL(err_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, stream, W, T, Q, total, (int)n,
+                           V, E);
+    }
     GANQ_LAUNCH_CHECK();
     int rc = ganq_matmul_f32(E, H, m, n, n, EH, stream_);
     if (rc) return rc;
-    hipLaunchKernelGGL(dot_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, EH, E, total, partial);
-    GANQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, stream, partial, loss_out);
+    {
+        ProfScope prof(KID_DOT, stream);
+        hipLaunchKernelGGL(dot_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, EH, E, total, partial);
+        hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, stream, partial, loss_out);
+    }
     GANQ_LAUNCH_CHECK();
     return 0;
 }
@@ -122,6 +127,7 @@ extern "C" int ganq_dequant_losses(const float* W, const float* T, const uint8_t
     if (Losses_out && (!W || !hinv_diag)) return fail(-3, "ganq_dequant_losses: Losses needs W and hinv_diag");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t total = m * n;
+    ProfScope prof(KID_DEQUANT, stream);
     hipLaunchKernelGGL(dequant_losses_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, T, Q,
                        hinv_diag, total, (int)n, V, Wq_out, Losses_out);
     GANQ_LAUNCH_CHECK();

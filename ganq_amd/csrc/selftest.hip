@@ -72,7 +72,7 @@ extern "C" int ganq_hip_selftest(void* stream_) {
     }
     if (e == hipSuccess) e = hipMemcpyAsync(hD, dD, sizeof(hD), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    hipFree(dbuf);
+    (void)hipFree(dbuf);
     if (e != hipSuccess) return fail(-100, "mfma probe failed: %s", hipGetErrorString(e));
     int asc = 0, desc = 0, differ = 0;
     for (int i = 0; i < 16; ++i)

@@ -230,6 +230,7 @@ extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const f
     if (rc) return rc;
     const int tiles = (int)((m + SR - 1) / SR);
     float* errt = static_cast<float*>(workspace);
+    ProfScope prof(KID_SOLVE_S, stream);
     if (mfma_k_ascending()) {
         hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(256), 0, stream, W, L, ldl, T, (int)m, (int)n, V,
                            Q_out, Err_out, errt);

@@ -444,8 +444,11 @@ extern "C" int ganq_update_t(const float* WH, const float* H, const uint8_t* Q, 
     float* mws = reinterpret_cast<float*>(ws + lo.off_mws);
 
     const int64_t items = m * ntile;
-    hipLaunchKernelGGL(sort_codes_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, Q, (int)m, (int)n,
-                       (int)ntile, sorted_off, seg);
+    {
+        ProfScope prof(KID_SORT_CODES, stream);
+        hipLaunchKernelGGL(sort_codes_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, Q, (int)m, (int)n,
+                           (int)ntile, sorted_off, seg);
+    }
     GANQ_LAUNCH_CHECK();
 
     static bool attr_set = false;
@@ -456,12 +459,17 @@ extern "C" int ganq_update_t(const float* WH, const float* H, const uint8_t* Q, 
         attr_set = true;
     }
     const dim3 grid((unsigned)nchunk, (unsigned)((m + TR - 1) / TR));
-    hipLaunchKernelGGL(sht_accum_kernel, grid, dim3(TW * 64), smem, stream, H, Q, sorted_off, seg, (int)m, (int)n,
-                       (int)ntile, mws, mfma_k_ascending());
+    {
+        ProfScope prof(KID_SHT_ACCUM, stream);
+        hipLaunchKernelGGL(sht_accum_kernel, grid, dim3(TW * 64), smem, stream, H, Q, sorted_off, seg, (int)m, (int)n,
+                           (int)ntile, mws, mfma_k_ascending());
+    }
     GANQ_LAUNCH_CHECK();
-
-    hipLaunchKernelGGL(solve_kernel, dim3((unsigned)((m + 3) / 4)), dim3(64), 0, stream, mws, (int)nchunk, H, WH, Q,
-                       (int)m, (int)n, V, rcond, T_out, A_out, b_out);
+    {
+        ProfScope prof(KID_T_SOLVE, stream);
+        hipLaunchKernelGGL(solve_kernel, dim3((unsigned)((m + 3) / 4)), dim3(64), 0, stream, mws, (int)nchunk, H, WH, Q,
+                           (int)m, (int)n, V, rcond, T_out, A_out, b_out);
+    }
     GANQ_LAUNCH_CHECK();
     return 0;
 }

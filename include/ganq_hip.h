@@ -100,12 +100,27 @@ int ganq_run_layer(const float* W, const float* H, const float* L, int64_t ldl, 
  * y[M,m] = x[M,n] @ dequant(qweight, lut)^T + bias.   dtype: 0 = fp16, 1 = bf16 (x, lut, bias, y).
  * qweight: indices packed `bits` per index along the in_features dimension in the GPTQ int32
  * layout qweight[n*bits/32, m] (qlinear/__init__.py:508-517); lut [m,V]; bias [m] or NULL.     */
+/* decode path, M <= 16 rows; workspace: ganq_lut_linear_workspace_bytes() */
+size_t ganq_lut_linear_workspace_bytes(int64_t M, int64_t m, int64_t n, int bits);
 int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, const void* bias, int dtype,
-                        int64_t M, int64_t m, int64_t n, int bits, void* y, void* stream);
+                        int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace, size_t workspace_bytes,
+                        void* stream);
+/* prefill path: materialise Wq [m,n] = lut[o][index] in the activation dtype for a library GEMM */
+int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dtype, int64_t m, int64_t n, int bits, void* Wq_out,
+                     void* stream);
 
 /* pack Q [m,n] uint8 (original column order) into qweight [n*bits/32, m] int32, and back */
 int ganq_pack_indices(const uint8_t* Q, int64_t m, int64_t n, int bits, int32_t* qweight, void* stream);
 int ganq_unpack_indices(const int32_t* qweight, int64_t m, int64_t n, int bits, uint8_t* Q, void* stream);
+
+/* ---- per-kernel device timing (HIP events recorded on the caller's stream around every kernel launch) ----
+ * ganq_profile_enable(1) starts collecting, ganq_profile_get() sums what has completed: the caller must have
+ * synchronised the stream.  kernel ids are 0 .. ganq_profile_num_kernels()-1.                              */
+int ganq_profile_enable(int on);
+int ganq_profile_reset(void);
+int ganq_profile_num_kernels(void);
+const char* ganq_profile_kernel_name(int kernel_id);
+int ganq_profile_get(int kernel_id, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

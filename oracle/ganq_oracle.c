@@ -408,12 +408,29 @@ int ganq_oracle_kmeans_row(const float* w, const double* weights, int64_t n, int
     double* cw = pre;
     double* cwx = pre + (n + 1);
     double* cwxx = pre + 2 * (n + 1);
-    cw[0] = cwx[0] = cwxx[0] = 0.0;
-    for (int64_t u = 0; u < n; ++u) {
-        double x = pairs[3 * u], ww = pairs[3 * u + 1];
-        cw[u + 1] = cw[u] + ww;
-        cwx[u + 1] = cwx[u] + ww * x;
-        cwxx[u + 1] = cwxx[u] + ww * x * x;
+    /* two-level summation (chunks of 16 summed left to right, chunk totals accumulated left to right): the
+     * association order the GPU kernel uses, so both produce the same fp64 prefix sums */
+    {
+        double oa = 0.0, ob = 0.0, od = 0.0;
+        for (int64_t c0 = 0; c0 < n; c0 += 16) {
+            double a = 0.0, b = 0.0, d = 0.0;
+            int64_t hi = c0 + 16 < n ? c0 + 16 : n;
+            for (int64_t u = c0; u < hi; ++u) {
+                cw[u] = oa + a;
+                cwx[u] = ob + b;
+                cwxx[u] = od + d;
+                double x = pairs[3 * u], ww = pairs[3 * u + 1];
+                a += ww;
+                b += ww * x;
+                d += ww * x * x;
+            }
+            oa += a;
+            ob += b;
+            od += d;
+        }
+        cw[n] = oa;
+        cwx[n] = ob;
+        cwxx[n] = od;
     }
     km_prefix p = {cw, cwx, cwxx};
     for (int64_t i = 0; i < n; ++i) {

@@ -1,0 +1,144 @@
+"""GPU parity tests for the kernels either side of the loop: Hessian accumulation (a1), codebook
+initialisation (a3), index packing and the LUT-dequant linear forward (a9) -- through the C-ABI, against the
+CPU oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from ganq_amd import _lib
+
+    assert torch.cuda.is_available()
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import c_oracle
+
+    return c_oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------------------------------ Hessian
+@pytest.mark.parametrize("name", golden_names())
+def test_hessian_golden(hip, name):
+    g = load_golden(name)
+    X = g["X"]  # [nb, bsz, seq, n] fp16
+    n = X.shape[-1]
+    H = torch.zeros(n, n, device="cuda")
+    N = 0
+    for b in range(X.shape[0]):
+        xb = dev(X[b].reshape(-1, n))
+        hip.hessian_accum(H, xb, N, X.shape[1])
+        N += X.shape[1]
+    Hn = H.cpu().numpy()
+    assert np.array_equal(Hn, Hn.T)
+    assert rel_fro(Hn, g["H_raw"]) < 1e-6
+
+
+@pytest.mark.parametrize("rows,n,dtype", [(100, 72, torch.float16), (333, 264, torch.bfloat16), (2048, 512, torch.float16)])
+def test_hessian_vs_oracle_shapes(hip, oracle, rows, n, dtype):
+    g = torch.Generator().manual_seed(rows + n)
+    X1 = torch.randn(rows, n, generator=g).to(dtype)
+    X2 = torch.randn(rows // 2, n, generator=g).to(dtype)
+    H = torch.full((n, n), 7.0, device="cuda")  # stale contents must be ignored on the first batch
+    hip.hessian_accum(H, X1.cuda(), 0, 3)
+    hip.hessian_accum(H, X2.cuda(), 3, 2)
+    ref = (2.0 / 5.0) * (X1.double().T @ X1.double() + X2.double().T @ X2.double())
+    assert rel_fro(H.cpu().numpy(), ref.numpy()) < 1e-6
+    if dtype == torch.float16:
+        Ho = np.zeros((n, n), dtype=np.float32)
+        oracle.hessian_accum(Ho, X1.numpy(), 0, 3)
+        oracle.hessian_accum(Ho, X2.numpy(), 3, 2)
+        assert rel_fro(H.cpu().numpy(), Ho) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ k-means
+@pytest.mark.parametrize("m,n,V,seed", [(8, 64, 4, 1), (32, 300, 16, 2), (16, 1024, 8, 3), (5, 4096, 16, 4), (3, 17, 16, 5)])
+def test_kmeans_vs_oracle(hip, oracle, m, n, V, seed):
+    rng = np.random.default_rng(seed)
+    W = (0.02 * rng.standard_normal((m, n))).astype(np.float16).astype(np.float32)
+    wts = rng.uniform(0.2, 3.0, n) ** -4
+    T0 = hip.kmeans_init(dev(W), torch.from_numpy(wts), V).cpu().numpy()
+    ref = oracle.kmeans_init(W, wts, V)
+    assert rel_fro(T0, ref) < 1e-6, np.abs(T0 - ref).max()
+    assert np.all(np.diff(T0, axis=1) >= 0)
+
+
+def test_kmeans_golden_T0(hip):
+    for name in golden_names():
+        g = load_golden(name)
+        V = 2 ** int(g["bits"])
+        wts = g["Hinv_diag"].astype(np.float32) ** -4  # ganq.py:427-429 (float32 power, then numpy)
+        T0 = hip.kmeans_init(dev(g["W_perm"]), torch.from_numpy(wts.astype(np.float64)), V).cpu().numpy()
+        assert rel_fro(T0, g["T"][0]) < 1e-6, name
+
+
+# ------------------------------------------------------------------------------------------ packing / LUT linear
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_pack_roundtrip_and_layout(hip, bits):
+    rng = np.random.default_rng(bits)
+    m, n = 48, 160
+    Q = rng.integers(0, 2 ** bits, size=(m, n), dtype=np.uint8)
+    qw = hip.pack_indices(dev(Q), bits)
+    assert qw.shape == (n * bits // 32, m) and qw.dtype == torch.int32
+    assert np.array_equal(hip.unpack_indices(qw, n, bits).cpu().numpy(), Q)
+    # the GPTQ int32 layout (qlinear/__init__.py:508-538): a little-endian bit stream along in_features
+    ref = np.zeros((n * bits // 32, m), dtype=np.uint64)
+    for e in range(n):
+        pos = e * bits
+        w, sh = pos // 32, pos % 32
+        v = Q[:, e].astype(np.uint64) << np.uint64(sh)
+        ref[w] |= v & np.uint64(0xFFFFFFFF)
+        if sh + bits > 32:
+            ref[w + 1] |= v >> np.uint64(32)
+    assert np.array_equal(qw.cpu().numpy().view(np.uint32), ref.astype(np.uint32))
+
+
+@pytest.mark.parametrize("bits,M,dtype", [(4, 1, torch.float16), (4, 5, torch.float16), (3, 2, torch.bfloat16),
+                                          (2, 8, torch.float16), (4, 16, torch.bfloat16)])
+def test_lut_linear_vs_dense(hip, oracle, bits, M, dtype):
+    rng = np.random.default_rng(bits * 100 + M)
+    m, n, V = 200, 512, 2 ** bits
+    Q = rng.integers(0, V, size=(m, n), dtype=np.uint8)
+    lut = torch.from_numpy((0.02 * rng.standard_normal((m, V))).astype(np.float32)).to(dtype)
+    x = torch.from_numpy(rng.standard_normal((M, n)).astype(np.float32)).to(dtype)
+    bias = torch.from_numpy((0.1 * rng.standard_normal(m)).astype(np.float32)).to(dtype)
+    qw = hip.pack_indices(dev(Q), bits)
+    y = hip.lut_linear(x.cuda(), qw, lut.cuda(), bias.cuda(), bits).cpu()
+    Wq = torch.gather(lut.float(), 1, torch.from_numpy(Q.astype(np.int64)))
+    ref = x.double() @ Wq.double().T + bias.double()
+    # one rounding to the activation dtype on top of an fp32 accumulation
+    eps = 2 ** -10 if dtype == torch.float16 else 2 ** -7
+    assert torch.allclose(y.double(), ref, rtol=eps, atol=eps * float(ref.abs().max()) * 0.05 + 1e-6)
+    assert torch.equal(hip.lut_dequant(qw, lut.cuda(), n, bits).cpu(), Wq.to(dtype))
+    if dtype == torch.float16:
+        yo = oracle.lut_linear(x.numpy(), Q, lut.numpy(), bias.numpy())
+        assert np.allclose(y.float().numpy(), yo, rtol=eps, atol=eps * 0.05 * np.abs(yo).max() + 1e-6)
+
+
+def test_lut_linear_golden_forward(hip):
+    # G7: FakeQuantLinear.forward (fake.py:88-89) on the reference's own quantized weight
+    for name in golden_names():
+        g = load_golden(name)
+        if int(g["n"]) % 32 or not (bool(g["desc_act"]) or str(g["act_sort"]) == "none"):
+            continue
+        K, bits = int(g["K"]), int(g["bits"])
+        best_k = int(np.argmin(g["dists"]))
+        Q = g["Q"][K - 1][:, np.argsort(g["perm"])]  # back to the original column order (gptq.py:341-343)
+        lut = torch.from_numpy(g["T"][best_k + 1]).half()
+        qw = hip.pack_indices(dev(Q), bits)
+        y = hip.lut_linear(dev(g["x_fwd"]), qw, lut.cuda(), dev(g["bias"]), bits).cpu().float().numpy()
+        ref = g["y_fwd"].astype(np.float32)
+        assert np.allclose(y, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max()), name

@@ -45,10 +45,17 @@ def test_no_cpu_fallback():
 
 
 def test_product_does_not_import_oracle():
+    """the oracle is test infrastructure: nothing under ganq_amd/ may import, link or call it (comments may cite it)"""
     pkg = os.path.join(ROOT, "ganq_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cc", ".cpp")):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "import oracle" not in src and "from oracle" not in src, f
-                assert "libganq_oracle" not in src and "ganq_oracle_" not in src.replace("ganq_oracle_solve_s)", ""), f
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                src = open(path).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "libganq_oracle" not in src, f
+            elif f.endswith((".hip", ".h", ".cc", ".cpp")) or f == "Makefile":
+                src = open(path).read()
+                src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+                src = re.sub(r"//[^\n]*", "", src)
+                assert "ganq_oracle" not in src and "oracle/" not in src, f
