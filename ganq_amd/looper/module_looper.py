@@ -1,0 +1,81 @@
+"""Layer-by-layer calibration driver: the caller of the hot path (reference gptqmodel/looper/module_looper.py:
+129-452), kept on the device end to end.
+
+For every decoder layer and every module group inside it (`layer_modules`, e.g. [[q,k,v],[o],[fc1],[fc2]],
+models/definitions/opt.py:36-41): install forward hooks -> run all calibration batches through the layer
+(hooks stream activations into GANQ.add_batch) -> processor.process(module) for every module of the group ->
+after the last group, re-run the batches through the now-quantized layer to produce the next layer's inputs
+(module_looper.py:354-396).  Unlike the reference, activations never bounce through host memory
+(module_looper.py:289-302).
+
+With torch.distributed initialised, the modules of a group -- which share their calibration inputs -- are
+dealt to the ranks (ganq_amd.distributed.assign) and their results broadcast back, so every rank continues
+with identical quantized layers ("looper dispatches layers over RCCL ranks").
+"""
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import distributed as gdist
+from .named_module import NamedModule
+
+
+def find_modules(layer: nn.Module, names: Sequence[str]) -> Dict[str, nn.Module]:
+    named = dict(layer.named_modules())
+    return {n: named[n] for n in names if n in named}
+
+
+class ModuleLooper:
+    def __init__(self, processor, layers: Sequence[nn.Module], layer_modules: List[List[str]],
+                 layers_prefix: str = "model.layers"):
+        self.processor = processor
+        self.layers = layers
+        self.layer_modules = layer_modules
+        self.layers_prefix = layers_prefix
+
+    @torch.no_grad()
+    def loop(self, layer_inputs: List[torch.Tensor], layer_kwargs: Optional[List[dict]] = None,
+             forward: Optional[Callable] = None, progress: Optional[Callable] = None):
+        """layer_inputs: hidden states entering layer 0, one tensor per calibration batch ([b, seq, hidden]);
+        layer_kwargs: per-batch keyword arguments of the layer forward (attention mask, position ids, ...).
+        Returns the hidden states leaving the last layer."""
+        layer_kwargs = layer_kwargs or [{} for _ in layer_inputs]
+        fwd = forward or (lambda layer, x, kw: layer(x, **kw))
+        dist = gdist.Dist.current()
+        for li, layer in enumerate(self.layers):
+            for names in self.layer_modules:
+                mods = find_modules(layer, names)
+                if not mods:
+                    continue
+                named = {n: NamedModule(m, name=n, full_name=f"{self.layers_prefix}.{li}.{n}", layer_index=li)
+                         for n, m in mods.items()}
+                owners = gdist.assign({n: (nm.state["out_features"], nm.state["in_features"])
+                                       for n, nm in named.items()}, dist.world)
+                mine = [n for n in named if owners[n] == dist.rank]
+                handles = []
+                for n in mine:
+                    self.processor.preprocess(named[n], buffered_fwd=False)
+                    if not self.processor.is_skipped(named[n]):
+                        handles.append(mods[n].register_forward_hook(self.processor.preprocess_fwd_hook(n)))
+                for x, kw in zip(layer_inputs, layer_kwargs):
+                    fwd(layer, x, kw)
+                for h in handles:
+                    h.remove()
+                for n in mine:
+                    if self.processor.is_skipped(named[n]):
+                        continue
+                    if self.processor.tasks[n].fwd_counter == 0:  # module never hit (module_looper.py:335-343)
+                        raise RuntimeError(f"module {named[n].full_name} saw no calibration activations")
+                    self.processor.process(named[n])
+                    if progress:
+                        progress(named[n])
+                if dist.world > 1:
+                    for n in named:  # owner broadcasts its result so every rank holds the quantized group
+                        gdist.share_module_result(self.processor, named[n], owners[n], dist)
+            outs = []
+            for x, kw in zip(layer_inputs, layer_kwargs):
+                y = fwd(layer, x, kw)
+                outs.append(y[0] if isinstance(y, (tuple, list)) else y)
+            layer_inputs = outs
+        return layer_inputs

@@ -1,0 +1,78 @@
+"""GANQ quantizer whose `_perform_quantization_loop` runs on the MI355X through libganq_hip.so.
+
+Drop-in for `gptqmodel.quantization.ganq.GANQ` (ganq.py:397-646): same constructor, same override point and
+return contract `(Wq, Losses, scale: list, zero: list)`, same config fields (`bits`, `ganq_iterations`, ...).
+Additionally keeps what the reference throws away (ganq.py:633-634,646): after `quantize()`,
+`self.ganq_indices` (uint8 [m,n], original column order) and `self.ganq_codebook` (fp32 [m,V]) hold the
+assignment and the per-row codebook that `GanqHipQuantLinear` packs.
+"""
+import time
+
+import torch
+
+from .. import _lib
+from .gptq import GPTQ
+
+
+class GANQ(GPTQ):
+    """Quantize following "GANQ: GPU-Adaptive Layer-Wise LUT-Based Non-Uniform Quantization" (arXiv 2501.12956)."""
+
+    def __init__(self, module, qcfg=None):
+        super().__init__(module, qcfg)
+        self.iterations = getattr(self.qcfg, "ganq_iterations", 5)
+        self.ganq_indices = None
+        self.ganq_codebook = None
+        self.ganq_stats = {}
+
+    def _initialize_codebook_kmeans(self, W, Hinv, num_bits, device):
+        """ganq.py:423-438: weighted 1-D k-means per row, column weight diag(Hinv)^-4 (computed in fp32 as the
+        reference does before handing it to kmeans1d, which works in double)."""
+        exp = 4
+        col_weight = (torch.diagonal(Hinv) ** (-exp)).double()
+        return _lib.kmeans_init(W, col_weight, 2 ** num_bits)
+
+    @torch.no_grad()
+    def _perform_quantization_loop(self, W, Hinv, blocksize, perm=None, invperm=None):
+        """Algorithm 1 of the paper as implemented by ganq.py:456-646, on the device:
+        T0 = k-means;  K x (S-solve, T-update, loss);  best-of-K;  Wq, Losses."""
+        num_bits = self.qcfg.bits
+        V = 2 ** num_bits
+        if num_bits not in (2, 3, 4):
+            raise NotImplementedError(f"GANQ HIP path implements bits in (2, 3, 4); got bits={num_bits}")
+
+        scale, zero = [], []
+        if self.qcfg.group_size != -1:  # "Not supported, here for compatibility" (ganq.py:489-495)
+            self.quantizer.find_params(W, weight=True)
+            scale.append(self.quantizer.scale)
+            zero.append(self.quantizer.zero)
+
+        t0 = time.perf_counter()
+        T0 = self._initialize_codebook_kmeans(W, Hinv, num_bits, W.device)
+        assert T0.shape == (W.shape[0], V)
+        alias = bool(getattr(self.qcfg, "ganq_reference_q_alias", True))
+        T, Q, dists, best_k = _lib.run_layer(W, self.Xxt_damped, self.L, T0, self.iterations, alias_q=alias)
+        Wq, Losses = _lib.dequant_losses(W, T, Q, torch.diagonal(Hinv).contiguous())
+        self.ganq_indices = Q          # permuted column order until quantize() un-permutes it
+        self.ganq_codebook = T
+        self.ganq_stats = {"dists": dists, "best_k": best_k, "enqueue_s": time.perf_counter() - t0}
+
+        if not scale:  # "Unused, compatibility with interface" (ganq.py:640-644)
+            self.quantizer.find_params(W, weight=True)
+            scale.append(self.quantizer.scale)
+            zero.append(self.quantizer.zero)
+        return Wq, Losses, scale, zero
+
+    def _unpermute_state(self, invperm):
+        # gptq.py:341-343 un-permutes Wq only when desc_act is set; the indices follow the same rule so that
+        # T.gather(1, Q) always equals the returned weight
+        if invperm is not None and self.ganq_indices is not None:
+            self.ganq_indices = self.ganq_indices[:, invperm].contiguous()
+
+    def make_quantized_weight(self, Q, T):
+        return T.gather(1, Q.long())
+
+    def free(self):
+        super().free()
+
+
+__all__ = ["GANQ"]

@@ -1,0 +1,223 @@
+"""GPTQ base class for the GANQ path: weight clone, Hessian accumulation, prologue (dead columns, act_sort,
+ganq-/gptq-style Cholesky, damping, inverse-Cholesky) and epilogue of `quantize()`.
+
+Host-side mirror of gptqmodel/quantization/gptq.py:42-393 with the same public surface
+(`GPTQ(module, qcfg)`, `add_batch`, `quantize() -> 7-tuple`, `hf_quantize`, `free`, override point
+`_perform_quantization_loop`).  What differs from the reference:
+  * the Hessian update of `process_batch` (gptq.py:122-131) runs in the HIP kernel ganq_hessian_accum;
+  * everything lives on the GPU; there is no CPU fallback (the module must be on a cuda device);
+  * GPTQ's own uniform-grid column loop (gptq.py:164-236) is NOT part of this path: only the GANQ subclass
+    implements `_perform_quantization_loop`.
+The dense factorizations (Cholesky, cholesky_inverse) are library LAPACK calls through torch on the device,
+as in the reference.
+"""
+import math
+import time
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..looper.named_module import NamedModule
+from .config import QuantizeConfig
+from .quantizer import HF_OPTIMUM, Quantizer
+
+
+def _is_conv1d(module) -> bool:
+    return type(module).__name__ == "Conv1D"  # transformers.pytorch_utils.Conv1D, without importing transformers
+
+
+class GPTQ:
+    def __init__(self, module: nn.Module, qcfg: Optional[QuantizeConfig] = None):
+        if isinstance(module, NamedModule):
+            self.module = module.module
+            name = module.name
+        else:
+            name = HF_OPTIMUM
+            self.module = module
+        if not isinstance(self.module, nn.Linear) and not _is_conv1d(self.module):
+            raise NotImplementedError(f"GANQ HIP path supports nn.Linear / Conv1D modules, got {type(self.module)}")
+        self.qcfg = qcfg if qcfg else QuantizeConfig()
+        self.device = self.module.weight.device
+        if self.device.type != "cuda":
+            raise _lib.GanqHipError(f"module `{name}` lives on {self.device}: the HIP quantizer needs it on the GPU "
+                                    f"(there is no CPU fallback)")
+        self.module_copy = self._clone_module()
+        self.rows, self.columns = self.module_copy.shape[0], self.module_copy.shape[1]
+        self.nsamples = 0
+        self.quantizer = self.create_quantizer(name=name)
+        self.fwd_inputs_buffered = False
+        self.fwd_inputs_buffered_data = []
+        self.fwd_counter = 0
+
+    def create_quantizer(self, name: str) -> Quantizer:
+        return Quantizer(qcfg=self.qcfg, name=name)
+
+    def shape(self):
+        return self.module.weight.shape if hasattr(self, "module") else (0, 0)
+
+    def _clone_module(self):
+        clone = self.module.weight.data.clone()
+        if _is_conv1d(self.module):
+            clone = clone.t()
+        return clone.float().contiguous()
+
+    # ---- gptq.py:88-131 --------------------------------------------------------------------------------
+    def add_batch(self, inp, out):
+        self.fwd_counter += 1
+        if self.fwd_inputs_buffered:
+            self.fwd_inputs_buffered_data.append(inp.to(device="cpu"))
+        else:
+            self.process_batch(inp)
+
+    def process_batch(self, inp):
+        inp = inp.to(device=self.device)
+        if len(inp.shape) == 2:
+            inp = inp.unsqueeze(0)
+        batch = inp.shape[0]  # sequences, not tokens (gptq.py:104)
+        if len(inp.shape) == 3:
+            inp = inp.reshape((-1, inp.shape[-1]))
+        if not hasattr(self, "H"):
+            self.H = torch.zeros((self.columns, self.columns), device=self.device)
+        if inp.dtype in (torch.float16, torch.bfloat16):
+            _lib.hessian_accum(self.H, inp, self.nsamples, batch)
+        else:
+            # fp32 activations: exact fp32 products on the fp32 matrix cores
+            x = inp.float().contiguous()
+            total = self.nsamples + batch
+            upd = _lib.matmul_f32(x.t().contiguous(), x)
+            self.H.mul_(self.nsamples / total).add_(upd, alpha=2.0 / total)
+        self.nsamples += batch
+
+    # ---- HF/optimum entry (gptq.py:133-162) --------------------------------------------------------------
+    def fasterquant(self, blocksize=128, percdamp=0.01, damp_auto_increment=0.0015, group_size=-1, actorder=False,
+                    static_groups=False):
+        return self.hf_quantize(blocksize, percdamp, damp_auto_increment, group_size, actorder, static_groups)
+
+    def hf_quantize(self, blocksize=128, percdamp=0.01, damp_auto_increment=0.0015, group_size=-1, actorder=False,
+                    static_groups=False):
+        self.qcfg.group_size = group_size
+        self.qcfg.damp_percent = percdamp
+        self.qcfg.damp_auto_increment = damp_auto_increment
+        self.qcfg.desc_act = actorder
+        self.qcfg.static_groups = static_groups
+        (Q, scale, zero, g_idx, duration, avg_loss, damp_percent) = self.quantize(blocksize=blocksize)
+        self.module.weight.data = Q
+        return scale, zero, g_idx, duration, avg_loss, damp_percent
+
+    def _perform_quantization_loop(self, W, Hinv, blocksize, perm=None, invperm=None):
+        raise NotImplementedError("the uniform-grid GPTQ column loop (gptq.py:164-236) is outside this path; "
+                                  "use ganq_amd.quantization.GANQ")
+
+    # ---- gptq.py:238-375 ---------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def quantize(self, blocksize=128):
+        start = time.time()
+        for inp in self.fwd_inputs_buffered_data:
+            self.process_batch(inp)
+        self.fwd_inputs_buffered_data = []
+
+        if self.module_copy is None:
+            W = self._clone_module()
+        else:
+            W = self.module_copy
+            self.module_copy = None
+        if not hasattr(self, "H"):
+            raise RuntimeError("quantize() called before any add_batch(): no calibration activations were seen")
+
+        self.quantizer.find_params(W, weight=True)
+
+        H = self.H
+        del self.H
+        dead = torch.diag(H) == 0
+        H[dead, dead] = 1
+        if self.qcfg.dead == "zero":
+            W[:, dead] = 0
+        elif self.qcfg.dead == "mean":
+            W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
+        else:
+            assert False, f"Unknown dead mode: {self.qcfg.dead}"
+
+        perm = None
+        invperm = None
+        if self.qcfg.act_sort != "none":
+            assert self.qcfg.act_sort in ["asc", "desc"]
+            perm = torch.argsort(torch.diag(H), descending=self.qcfg.act_sort == "desc")
+            W = W[:, perm].contiguous()
+            H = H[perm][:, perm].contiguous()
+            invperm = torch.argsort(perm)
+
+        self.Xxt = H.clone()  # undamped
+        if self.qcfg.l_damp_style == "ganq":
+            offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
+            self.L = torch.linalg.cholesky(H + torch.diag(offset))
+
+        damp_percent = self.qcfg.damp_percent
+        Hinv = None
+        while 1 > damp_percent > 0:
+            try:
+                damp = damp_percent * torch.mean(torch.diag(H))
+                diag = torch.arange(self.columns, device=self.device)
+                H[diag, diag] += damp
+                self.Xxt_damped = H.clone()
+                L = torch.linalg.cholesky(H)
+                if self.qcfg.l_damp_style == "gptq":
+                    self.L = L.clone()
+                Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
+                break
+            except torch._C._LinAlgError as e:
+                if self.qcfg.damp_auto_increment != 0:
+                    damp_percent += self.qcfg.damp_auto_increment
+                else:
+                    raise e
+        if not (0 < damp_percent < 1):
+            raise ValueError(f"Quantization: `damp_percent` must between 0 and 1. current is {damp_percent}")
+
+        Q, Losses, scale, zero = self._perform_quantization_loop(W, Hinv, blocksize, perm, invperm)
+
+        torch.cuda.synchronize(self.device)
+        avg_loss = torch.sum(Losses).item() / self.nsamples
+        if math.isnan(avg_loss):
+            raise ValueError("Quantization: Failed due to `NaN` loss")
+
+        group_size = self.qcfg.group_size if self.qcfg.group_size != -1 else self.columns
+        if self.qcfg.static_groups and self.qcfg.desc_act:
+            g_idx = (perm // group_size).to(dtype=torch.int32)
+        else:
+            g_idx = (torch.arange(self.columns, device=Q.device) // group_size).to(dtype=torch.int32)
+        if self.qcfg.desc_act:
+            # with act_sort == "none" the reference would index with invperm = None; the permutation is the identity
+            if invperm is not None:
+                Q = Q[:, invperm]
+                g_idx = g_idx[invperm]
+        self._unpermute_state(invperm if self.qcfg.desc_act else None)
+
+        if _is_conv1d(self.module):
+            Q = Q.t()
+        if Q.shape != self.module.weight.shape:
+            Q = Q.reshape(self.module.weight.shape).type_as(self.module.weight.data)
+        else:
+            Q = Q.type_as(self.module.weight.data)
+        Q = Q.to(device=self.device)
+
+        if scale == []:
+            scale.append(self.quantizer.scale)
+            zero.append(self.quantizer.zero)
+        scale = torch.cat(scale, dim=1)
+        zero = torch.cat(zero, dim=1)
+        duration = time.time() - start
+        return Q, scale, zero, g_idx, duration, avg_loss, damp_percent
+
+    def _unpermute_state(self, invperm):
+        pass
+
+    def free(self):
+        if hasattr(self, "H"):
+            del self.H
+        for name in ("quantizer", "module_copy", "module", "L", "Xxt", "Xxt_damped"):
+            if hasattr(self, name):
+                delattr(self, name)
+
+
+__all__ = ["GPTQ"]

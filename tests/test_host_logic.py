@@ -1,0 +1,143 @@
+"""CPU tests of the host-side mirror of the reference interface: config validation, QuantLinear capability
+checks, codebook recovery, work assignment, and the N>1 collective logic under gloo (world_size 2) with the
+compute calls served by the CPU oracle (tests may use the oracle; the product path never does)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from ganq_amd import distributed as gdist  # noqa: E402
+from ganq_amd.nn_modules.qlinear.ganq_hip import GanqHipQuantLinear  # noqa: E402
+from ganq_amd.quantization.config import FORMAT, QuantizeConfig  # noqa: E402
+
+
+def test_config_defaults_and_validation():
+    q = QuantizeConfig(bits=4, quant_method="ganq")
+    assert q.ganq_iterations == 5 and q.act_sort == "desc" and q.l_damp_style == "gptq" and q.dead == "zero"
+    assert QuantizeConfig(desc_act=False).act_sort == "none"  # config.py:275-276
+    for bad in (dict(bits=5), dict(damp_percent=1.5), dict(format="gptq"), dict(group_size=0), dict(pack_dtype="fp8")):
+        with pytest.raises(ValueError):
+            QuantizeConfig(**bad)
+    q = QuantizeConfig(dynamic={r"-:.*\.k_proj": {}, r".*\.fc1": {"bits": 3}})
+    assert q.dynamic_get("model.layers.0.k_proj") is False
+    assert q.dynamic_get("model.layers.0.fc1", "bits", 4) == 3
+    assert q.dynamic_get("model.layers.0.fc2", "bits", 4) == 4
+    assert QuantizeConfig.from_dict(q.to_dict()).dynamic == q.dynamic
+
+
+def test_quantlinear_validate_falls_through():
+    ok, err = GanqHipQuantLinear.validate(bits=4, group_size=128, desc_act=True, sym=True, in_features=4096,
+                                          out_features=4096, pack_dtype=torch.int32)
+    assert ok and err is None
+    for kw in (dict(bits=8), dict(in_features=100), dict(pack_dtype=torch.int16)):
+        args = dict(bits=4, group_size=128, desc_act=True, sym=True, in_features=4096, out_features=4096,
+                    pack_dtype=torch.int32)
+        args.update(kw)
+        ok, err = GanqHipQuantLinear.validate(**args)
+        assert not ok and isinstance(err, NotImplementedError)  # caller tries the next backend (utils/model.py:234-239)
+
+
+def test_codebook_from_weight_roundtrip():
+    g = torch.Generator().manual_seed(0)
+    T = torch.randn(12, 16, generator=g)
+    T[3, 5] = T[3, 4]  # duplicate entry
+    Q = torch.randint(0, 16, (12, 96), generator=g)
+    W = T.gather(1, Q).half()
+    Q2, T2 = GanqHipQuantLinear.codebook_from_weight(W, 4)
+    assert torch.equal(T2.gather(1, Q2.long()).half(), W)
+    with pytest.raises(ValueError):
+        GanqHipQuantLinear.codebook_from_weight(torch.randn(2, 64), 4)
+
+
+def test_assign_and_row_slices():
+    shapes = {"q_proj": (4096, 4096), "k_proj": (1024, 4096), "v_proj": (1024, 4096), "o_proj": (4096, 4096)}
+    for world in (1, 2, 3, 8):
+        owners = gdist.assign(shapes, world)
+        assert set(owners) == set(shapes) and all(0 <= r < world for r in owners.values())
+        if world >= 2:
+            assert owners["q_proj"] != owners["o_proj"]  # the two big ones never share a rank
+    for m, world in ((4096, 8), (100, 3), (16, 4), (5, 2)):
+        sl = gdist.row_slices(m, world)
+        assert sl[0][0] == 0 and sl[-1][1] == m and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+        assert all((a % 16 == 0) for a, _ in sl if a < m)
+
+
+class OracleSolver:
+    """CPU stand-in for HipSolver, for the gloo tests only"""
+
+    def __init__(self):
+        from oracle import c_oracle
+
+        self.o = c_oracle
+
+    def matmul(self, A, B):
+        return torch.from_numpy(self.o.matmul(A.numpy(), B.numpy()))
+
+    def solve_s(self, W, L, T):
+        return torch.from_numpy(self.o.solve_s(W.numpy(), L.numpy(), T.numpy()))
+
+    def update_t(self, WH, H, Q, V, rcond):
+        return torch.from_numpy(self.o.update_t(WH.numpy(), H.numpy(), Q.numpy(), V, rcond))
+
+    def quad_loss(self, W, H, T, Q):
+        return torch.tensor(self.o.quad_loss(W.numpy(), H.numpy(), T.numpy(), Q.numpy()), dtype=torch.float64)
+
+
+def _golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+
+def _worker(rank, world, port, name, alias, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import torch.distributed as td
+
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import c_oracle
+
+        c_oracle.set_num_threads(1)
+        g = _golden(name)
+        W, H, L = (torch.from_numpy(g[k]) for k in ("W_perm", "Xxt_damped", "L"))
+        T0 = torch.from_numpy(g["T"][0])
+        T, Q, dists, best_k = gdist.run_layer_row_sharded(W, H, L, T0, int(g["K"]), alias_q=alias,
+                                                          dist=gdist.Dist(rank, world, torch.device("cpu")),
+                                                          solver=OracleSolver())
+        # activation broadcast + Hessian all-reduce helpers
+        x = torch.arange(12.0).reshape(3, 4) if rank == 0 else None
+        xb = gdist.broadcast_activations(x, (3, 4), torch.float32, 0, gdist.Dist(rank, world, torch.device("cpu")))
+        Hp = torch.full((2, 2), float(rank + 1))
+        gdist.allreduce_hessian(Hp, gdist.Dist(rank, world, torch.device("cpu")))
+        out_q.put((rank, T.numpy(), Q.numpy(), dists.numpy(), best_k, xb.numpy(), Hp.numpy()))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,alias", [("b32x64_b3", True), ("b32x64_b3", False), ("t24x48_b2", True)])
+def test_row_sharded_two_ranks_gloo(name, alias):
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = 29600 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, alias, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((out_q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = _golden(name)
+    K = int(g["K"])
+    best = int(np.argmin(g["dists"]))
+    for rank, T, Q, dists, best_k, xb, Hp in res:
+        assert best_k == best
+        assert np.allclose(dists, g["dists"], rtol=1e-5)
+        assert np.array_equal(Q, g["Q"][K - 1] if alias else g["Q"][best])
+        assert np.linalg.norm(T - g["T"][best + 1]) / np.linalg.norm(g["T"][best + 1]) < 1e-5
+        assert np.array_equal(xb, np.arange(12.0).reshape(3, 4)) and np.all(Hp == 3.0)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
