@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: weight-columns quantized per second on the synthetic 4096x4096 layer
+(BASELINE.json metric; definition in SURVEY.md section 8(d)).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = the complete alternating optimisation of one 4096x4096 layer: K_iter = 10 x (S-solve, T-update,
+loss) + best-of-K, i.e. the body of GANQ._perform_quantization_loop after codebook init (ganq.py:525-634), with
+W, L, Xxt_damped and T0 already resident in HBM.  value = n_gpus * steps * 4096 / wall time of the timed region
+(barrier + synchronize on both sides, max over ranks).
+
+Multi-GPU (weak scaling, no data-path collective in the timed region): every rank quantizes its OWN layer of a
+group that shares one set of calibration activations (like q/k/v): rank 0 generates the 128 x 2048 x 4096 fp16
+activations and broadcasts them over RCCL/xGMI during setup, every rank accumulates the Hessian with the HIP
+kernel and quantizes its layer (seed = rank).  The broadcast time is reported in `setup`.
+
+Besides the driver contract the JSON line carries `roofline` (dominant kernel of the timed region, measured live
+with HIP events on the launch stream) and `cpu_baseline` (the torch restatement of the reference's own op
+sequence, oracle/ganq_ref.py, timed on this host on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_workload(args, dist, dev):
+    """synthetic layer of SURVEY 8(d): W = 0.02*randn (fp16-rounded), X = randn * (0.1 + rand(n)) in 128 chunks"""
+    import torch.distributed as td
+    import torch.nn as nn
+
+    from ganq_amd import _lib
+    from ganq_amd.looper.named_module import NamedModule
+    from ganq_amd.quantization import GANQ, QuantizeConfig
+
+    m, n = args.m, args.n
+    g = torch.Generator(device="cpu").manual_seed(0 + dist.rank)
+    lin = nn.Linear(n, m, bias=False).half()
+    with torch.no_grad():
+        lin.weight.copy_((0.02 * torch.randn(m, n, generator=g)).half())
+    lin = lin.to(dev)
+    qcfg = QuantizeConfig(bits=args.bits, quant_method="ganq", format="ganq_lut", act_sort="asc", l_damp_style="ganq",
+                          dead="mean", damp_percent=0.01, desc_act=True, group_size=128, ganq_iterations=args.iters)
+
+    captured = {}
+
+    class CaptureGANQ(GANQ):
+        def _perform_quantization_loop(self, W, Hinv, blocksize, perm=None, invperm=None):
+            captured.update(W=W.clone(), Hinv_diag=torch.diagonal(Hinv).clone(), L=self.L, H=self.Xxt_damped)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            T0 = self._initialize_codebook_kmeans(W, Hinv, self.qcfg.bits, W.device)
+            torch.cuda.synchronize()
+            captured["kmeans_s"] = time.perf_counter() - t0
+            captured["T0"] = T0
+            self._initialize_codebook_kmeans = lambda *a, **k: T0  # do not run it twice
+            out = super()._perform_quantization_loop(W, Hinv, blocksize, perm, invperm)
+            return out
+
+    q = CaptureGANQ(NamedModule(lin, "proj", f"model.layers.0.proj{dist.rank}", 0), qcfg)
+    q.quantizer.configure(perchannel=True)
+
+    gs = torch.Generator(device="cpu").manual_seed(999)
+    scale = (0.1 + torch.rand(n, generator=gs)).to(dev)
+    t_bcast = t_hess = 0.0
+    for b in range(args.nseq):
+        if dist.rank == 0:
+            gx = torch.Generator(device=dev).manual_seed(1000 + b)
+            x = (torch.randn(args.seqlen, n, generator=gx, device=dev) * scale).half()
+        else:
+            x = torch.empty((args.seqlen, n), dtype=torch.float16, device=dev)
+        if dist.world > 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            td.broadcast(x, src=0)  # RCCL over xGMI: calibration activations to every owner rank
+            torch.cuda.synchronize()
+            t_bcast += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        q.add_batch(x.unsqueeze(0), None)  # one sequence per call, as the looper's forward hook does
+        if b == args.nseq - 1:
+            torch.cuda.synchronize()
+        t_hess += time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wq, _, _, _, _, avg_loss, damp = q.quantize()  # full quantize(): prologue + k-means + loop + epilogue
+    torch.cuda.synchronize()
+    t_full = time.perf_counter() - t0
+    setup = {"hessian_s": round(t_hess, 4), "xgmi_broadcast_s": round(t_bcast, 4), "kmeans_s": round(captured["kmeans_s"], 4),
+             "full_quantize_s": round(t_full, 4), "avg_loss": avg_loss, "damp_percent": damp,
+             "calib_bytes": args.nseq * args.seqlen * n * 2}
+    return captured, setup
+
+
+def cpu_baseline(cap, args):
+    """the reference's own op sequence (torch CPU: per-column gather + gemv, lstsq/gelsd, quad loss) on a bounded
+    sample: `rows` rows of the same layer, one iteration; rows are independent, so layer time scales by m/rows."""
+    from oracle import c_oracle, ganq_ref
+
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    torch.set_num_threads(threads)
+    rows = min(args.cpu_rows, args.m)
+    W = cap["W"][:rows].cpu()
+    H, L, T0 = cap["H"].cpu(), cap["L"].cpu(), cap["T0"][:rows].cpu()
+    timings = []
+    t0 = time.perf_counter()
+    ganq_ref.run_layer(W, H, L, T0, 1, timings=timings)
+    t_ref = time.perf_counter() - t0
+    per_layer = t_ref * (args.m / rows) * args.iters
+    out = {"value": round(args.n / per_layer, 4), "unit": "columns/s", "cores": threads, "kind": "port",
+           "sample": f"torch op-sequence restatement of ganq.py:533-626 (oracle/ganq_ref.py), {rows} of {args.m} rows x "
+                     f"1 of {args.iters} iterations of the same {args.m}x{args.n} layer, {t_ref:.2f} s measured "
+                     f"(S-solve {timings[0][0]:.2f} s, T-update {timings[0][1]:.2f} s, loss {timings[0][2]:.2f} s), scaled "
+                     f"by rows and iterations",
+           "measured_s": round(t_ref, 3)}
+    # second, stronger CPU number: the canonical-order C oracle with OpenMP
+    c_oracle.set_num_threads(threads)
+    rows_c = min(4 * rows, args.m)
+    Wn, Hn, Ln, Tn = cap["W"][:rows_c].cpu().numpy(), H.numpy(), L.numpy(), cap["T0"][:rows_c].cpu().numpy()
+    t0 = time.perf_counter()
+    c_oracle.run_layer(Wn, Hn, Ln, Tn, 1)
+    t_c = time.perf_counter() - t0
+    out["c_oracle"] = {"value": round(args.n / (t_c * (args.m / rows_c) * args.iters), 4), "unit": "columns/s",
+                       "cores": threads, "sample": f"oracle/ganq_oracle.c, {rows_c} rows x 1 iteration, {t_c:.2f} s"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=10, help="GANQ iterations K (README PPL numbers use 10)")
+    ap.add_argument("--nseq", type=int, default=128)
+    ap.add_argument("--seqlen", type=int, default=2048)
+    ap.add_argument("--cpu-rows", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from ganq_amd import _lib
+    from ganq_amd import distributed as gdist
+
+    dist = gdist.init_from_env()
+    if dist.world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={dist.world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    dev = dist.device
+    _lib.selftest()
+    import torch.distributed as td
+
+    cap, setup = build_workload(args, dist, dev)
+    V = 2 ** args.bits
+    ws = _lib.run_layer_workspace(args.m, args.n, V, dev)
+
+    def step():
+        return _lib.run_layer(cap["W"], cap["H"], cap["L"], cap["T0"], args.iters, alias_q=True, workspace=ws)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist.world > 1:
+        td.barrier()
+    _lib.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist.world > 1:
+        td.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_report()
+    _lib.profile_enable(False)
+    if dist.world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if dist.rank == 0:
+        m, n, K = args.m, args.n, args.iters
+        value = dist.world * args.steps * n / elapsed
+        kern = {k: {"total_ms": round(v[0], 3), "launches": v[1], "avg_ms": round(v[0] / v[1], 4)} for k, v in prof.items()}
+        dom = max(prof.items(), key=lambda kv: kv[1][0])
+        dom_name, (dom_ms, dom_cnt) = dom
+        avg_s = dom_ms / dom_cnt / 1e3
+        if dom_name == "solve_s_kernel":
+            flops = float(m) * n * (n - 1)  # residual chain: n(n-1)/2 fused multiply-adds per row
+            roof = {"kernel": dom_name, "bound": "mfma", "achieved": round(flops / avg_s / 1e12, 3),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        elif dom_name == "gemm_f32_kernel":
+            flops = 2.0 * m * n * n
+            roof = {"kernel": dom_name, "bound": "mfma", "achieved": round(flops / avg_s / 1e12, 3),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        else:
+            # T-update accumulation: algorithmic bytes = H once (4 n^2) + Q (m n) + per-chunk partial A out
+            nbytes = 4.0 * n * n + 1.0 * m * n + 4.0 * m * V * V * ((n + 127) // 128)
+            roof = {"kernel": dom_name, "bound": "hbm", "achieved": round(nbytes / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s"}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 5)
+        roof["avg_launch_ms"] = round(dom_ms / dom_cnt, 4)
+        roof["traffic"] = None  # HBM bytes from PMC counters live in profiles/ (separate rocprofv3 --pmc pass)
+        # whole-path HBM view: algorithmic bytes of the loop per layer / loop time
+        b_loop = K * (15.0 * m * n + 10.0 * n * n + 8.0 * m * V)
+        path_gbs = b_loop / (elapsed / args.steps) / 1e9
+        result = {
+            "metric": "weight-columns quantized/sec @4096x4096 (GANQ 4-bit, K=10 alternating-optimisation loop)",
+            "value": round(value, 2), "unit": "columns/s", "n_gpus": dist.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {m}x{n} layer, {args.bits}-bit (V={V}), K={K}, act_sort=asc, "
+                                   f"l_damp_style=ganq, {args.nseq}x{args.seqlen} fp16 calibration tokens; one layer per GPU",
+                       "m": m, "n": n, "bits": args.bits, "ganq_iterations": K, "parallelism": f"layers x{dist.world}"},
+            "column_steps_per_s": round(value * K, 1),
+            "roofline": roof,
+            "path_hbm": {"algorithmic_GB_per_layer": round(b_loop / 1e9, 3), "achieved_GBs": round(path_gbs, 2),
+                         "frac_of_peak": round(path_gbs / HBM_PEAK_GBS, 5)},
+            "kernels": kern,
+            "setup": setup,
+            "dists_last_step": [round(float(x), 6) for x in out[2].cpu().tolist()], "best_k": int(out[3]),
+        }
+        if dist.world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cap, args)
+            result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
+        print(json.dumps(result), flush=True)
+    if dist.world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
