@@ -59,6 +59,7 @@ enum KernelId : int {
     KID_LUT_GEMV,
     KID_LUT_GEMM,
     KID_PACK,
+    KID_T_PREP,
     KID_COUNT
 };
 bool profile_enabled();

@@ -5,6 +5,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "update_t.h"
 
 namespace ganq {
 
@@ -56,8 +57,9 @@ static int launch_copy_if(const int32_t* flag, const void* src, void* dst, size_
 }
 
 struct RunLayout {
-    size_t off_wh, off_t0, off_t1, off_q, off_solve, off_upd, off_loss, off_best, off_flag, total;
-    size_t solve_bytes, upd_bytes, loss_bytes;
+    size_t off_t0, off_t1, off_q, off_solve, off_upd, off_best, off_flag, total;
+    size_t solve_bytes;
+    TLayout t;
 };
 
 static RunLayout run_layout(int64_t m, int64_t n, int V) {
@@ -69,15 +71,12 @@ static RunLayout run_layout(int64_t m, int64_t n, int V) {
         return o;
     };
     lo.solve_bytes = ganq_solve_s_workspace_bytes(m, n, V);
-    lo.upd_bytes = ganq_update_t_workspace_bytes(m, n, V);
-    lo.loss_bytes = ganq_quad_loss_workspace_bytes(m, n, V);
-    lo.off_wh = take((size_t)m * n * sizeof(float));
+    lo.t = t_layout(m, n, true);
     lo.off_t0 = take((size_t)m * V * sizeof(float));
     lo.off_t1 = take((size_t)m * V * sizeof(float));
     lo.off_q = take((size_t)m * n);
     lo.off_solve = take(lo.solve_bytes);
-    lo.off_upd = take(lo.upd_bytes);
-    lo.off_loss = take(lo.loss_bytes);
+    lo.off_upd = take(lo.t.total);
     lo.off_best = take(sizeof(double));
     lo.off_flag = take(sizeof(int32_t));
     lo.total = off;
@@ -107,7 +106,6 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
     int rc = ganq_hip_selftest(stream_);
     if (rc) return rc;
     char* ws = static_cast<char*>(workspace);
-    float* WH = reinterpret_cast<float*>(ws + lo.off_wh);
     float* Tc = reinterpret_cast<float*>(ws + lo.off_t0);
     float* Tn = reinterpret_cast<float*>(ws + lo.off_t1);
     uint8_t* Qc = reinterpret_cast<uint8_t*>(ws + lo.off_q);
@@ -117,7 +115,9 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
     // with the reference's aliasing the returned indices are simply those of the last iteration
     uint8_t* Qwork = alias ? Q_out : Qc;
 
-    rc = ganq_matmul_f32(W, H, m, n, n, WH, stream_);  // W @ H is iteration-invariant (ganq.py:590)
+    if (rcond < 0) rcond = 1.1920928955078125e-07 * (double)V;
+    // iteration-invariant part of the T-update / loss: fixed-point planes of H, W @ H and w^T H w in fp64 (ganq.py:590)
+    rc = t_prepare(W, H, m, n, lo.t, ws + lo.off_upd, true, stream);
     if (rc) return rc;
     GANQ_HIP_CHECK(hipMemcpyAsync(Tc, T0, (size_t)m * V * sizeof(float), hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(best_init_kernel, dim3(1), dim3(1), 0, stream, best, best_k, flag);
@@ -126,11 +126,10 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
     for (int k = 0; k < K; ++k) {
         rc = ganq_solve_s(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, lo.solve_bytes, stream_);
         if (rc) return rc;
-        rc = ganq_update_t(WH, H, Qwork, m, n, V, rcond, Tn, nullptr, nullptr, ws + lo.off_upd, lo.upd_bytes, stream_);
+        // new codebook and, from the same A and b, the loss of (new codebook, these indices)  (ganq.py:589-591, :621-622)
+        rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, dists + k, stream);
         if (rc) return rc;
         std::swap(Tc, Tn);
-        rc = ganq_quad_loss(W, H, Tc, Qwork, m, n, V, dists + k, ws + lo.off_loss, lo.loss_bytes, stream_);
-        if (rc) return rc;
         hipLaunchKernelGGL(best_select_kernel, dim3(1), dim3(1), 0, stream, dists + k, k, best, best_k, flag);
         GANQ_LAUNCH_CHECK();
         rc = launch_copy_if(flag, Tc, T_best, (size_t)m * V * sizeof(float), stream);

@@ -1,0 +1,23 @@
+// Internal interface of the T-update (update_t.hip) used by the loop driver (run_layer.hip).
+#pragma once
+#include "common.h"
+
+namespace ganq {
+
+struct TLayout {
+    int64_t nq, ng;  // padded plane row pitch, number of 64-column mask groups
+    size_t off_prep, off_planes, off_hdiag, off_bits, off_mpart, off_h64, off_wh64, off_whw, off_lossrows, total;
+};
+
+TLayout t_layout(int64_t m, int64_t n, bool with_f64);
+
+// once per layer.  with_f64: also W @ H_fixed in fp64 and w_i^T H w_i (needed for the closed-form loss)
+int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayout& lo, char* ws, bool with_f64,
+              hipStream_t stream);
+
+// once per iteration.  WH32 != nullptr: b from the caller's fp32 W@H (stage API, no loss);
+// WH32 == nullptr: b from the fp64 product prepared by t_prepare, loss_out (device double) optional
+int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
+              float* T_out, float* A_out, float* b_out, double* loss_out, hipStream_t stream);
+
+}  // namespace ganq

@@ -1,226 +1,249 @@
 // T-update: closed-form codebook update of GANQ (reference ganq.py:570-591, CPU/gelsd branch)
 //     A_i = S_i H S_i^T,  b_i = S_i (W H)_i^T,  T_i = minimum-norm lstsq(A_i, b_i)
+// and, from the same quantities, the loss of ganq.py:392-395 / :621-622
+//     dist = sum_i (w_i - S_i^T t_i)^T H (w_i - S_i^T t_i) = sum_i ( w_i^T H w_i - 2 t_i^T b_i + t_i^T A_i t_i )
 // without ever materialising the one-hot tensor S [m,V,n] (1 GiB at 4096^2, ganq.py:505).
 //
-// H is symmetric: A_i = M_i + M_i^T + diag_a( sum_{u in a} H[u,u] ) with
-//     M_i[a][b] = sum_{u > v} [Q_iu == a][Q_iv == b] H[u,v]      (strict lower triangle only).
-//
-// Kernels
-//   sort_codes_kernel   per (row, 256-row tile of H): counting sort of the tile's columns u by code
-//                       -> LDS byte offsets of the tile rows grouped by code (ascending u inside a code),
-//                       every code segment padded to a multiple of 8 with the offset of an all-zero row
-//   sht_accum_kernel    workgroup = (128-wide v chunk c, 32 rows of W).  Tiles of H [256 u x 128 v]
-//                       that reach below the diagonal are staged through LDS (entries with u <= v zeroed);
-//                       each wave owns 2 rows and keeps Yl[row][code][2 v per lane] in registers:
-//                       for code a: for u in tile with Q_iu == a: Yl[a] += H[u, chunk]   (ds_read_b64 + v_pk_add_f32)
-//                       The H tile is shared by 32 rows, the accumulator index is static (code-major
-//                       loops over the sorted lists, 8 independent LDS reads per batch).  Epilogue:
-//                       M_c = Yl @ onehot(Q_i[chunk])^T on the fp32 matrix cores (ordered, deterministic).
-//   solve_kernel        16 lanes per row: reduce the chunks in fixed order, add M^T and the diagonal term,
-//                       build b, eigen-decompose the 16x16 system with round-robin Jacobi in fp64 and
-//                       form the minimum-norm solution with the gelsd cut-off (rcond * |lambda|_max).
+// A_i[a][b] = sum_{u,v} [Q_iu == a][Q_iv == b] H[u,v] is a bucket sum of ALL of H per row: m*n^2 additions.
+// It runs on the integer matrix cores, exactly:
+//   * once per layer H is converted to 31-bit fixed point (scale = max|H| / 2^30) and split into 4 balanced
+//     base-256 digits, stored as 4 int8 planes Hq[p][v][u] (t_prepare);
+//   * per iteration the indices become bit masks bits[row][u/64][code] (one ballot per code);
+//   * v_mfma_i32_16x16x64_i8 multiplies the one-hot matrix [16 codes x 64 u] (expanded from 16 mask bits per lane
+//     with one integer multiply per 4 bytes) with a digit tile [64 u x 16 v]: int32 accumulators hold
+//     Y_p[a][v] = sum_{u in a, u > v} digit_p(H[v][u]).  Integer sums are exact and order-independent, so the
+//     result is deterministic whatever the scheduling;
+//   * the v index is bucketed with 64-bit LDS atomics (digits recombined to one int64 first), again exact;
+//   * H symmetric: only u > v is visited, A = M + M^T + diag.
+// The per-row 16x16 systems are then solved in fp64 (round-robin Jacobi, gelsd cut-off); with A exact and
+// b = S (W H) accumulated in fp64 the closed-form loss has no cancellation problem, so no (W-Wq)@H product is
+// needed per iteration.
 #include "common.h"
+#include "update_t.h"
 
 namespace ganq {
 
-constexpr int UT = 256;                 // rows of H per tile
-constexpr int VC = 128;                 // columns of H per chunk (2 per lane)
-constexpr int TW = 16;                  // waves per workgroup in sht_accum
-constexpr int RW = 2;                   // rows of W per wave
-constexpr int TR = TW * RW;             // rows of W per workgroup (32)
-constexpr int NB = 8;                   // sorted-list batch: every code segment is padded to a multiple of NB
-constexpr int LIST = NB * 64;           // sorted-list slots per (row, tile): [NB][64] uint32, entry e at [e % NB][e / NB]
-constexpr uint32_t ZERO_OFF = UT * VC * 4;  // LDS byte offset of the all-zero row that padding entries point to
-constexpr size_t ACCUM_TILE_BYTES = (size_t)(UT + 1) * VC * sizeof(float);
-constexpr size_t ACCUM_EPI_BYTES = (size_t)TW * 16 * (VC + 4) * sizeof(float);
-constexpr size_t ACCUM_SMEM = ACCUM_TILE_BYTES > ACCUM_EPI_BYTES ? ACCUM_TILE_BYTES : ACCUM_EPI_BYTES;
+constexpr int TR = 32;          // rows of W per workgroup
+constexpr int TW = 8;           // waves per workgroup
+constexpr int RW = 4;           // rows per wave
+constexpr int VCH = 32;         // v columns per chunk (two 16-wide MFMA column tiles)
+constexpr int UT = 256;         // u per staged tile (four 64-deep MFMA steps)
+constexpr int NP = 8;           // chunk c belongs to part c % NP; every part writes one partial A
+constexpr int BROW = UT + 16;   // LDS row pitch of a digit tile in bytes (pad against bank conflicts)
+constexpr int BTILE = 4 * VCH * BROW;
 
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sort_codes_kernel(const uint8_t* __restrict__ Q, int m, int n, int ntile,
-                                                         uint32_t* __restrict__ sorted_off,
-                                                         uint8_t* __restrict__ seg_start) {
-    // one wave per (row, tile): counting sort of the tile's 256 columns by code, ascending column inside a code
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct TPrep {              // device-side header written by t_prepare
+    double scale;           // H ~= scale * integer
+    unsigned int absmax_bits;
+    unsigned int pad;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ H, int64_t total, TPrep* __restrict__ prep) {
+    unsigned int mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        mx = max(mx, __builtin_bit_cast(unsigned int, H[i]) & 0x7fffffffu);  // |x| bits order like the values
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&prep->absmax_bits, mx);
+}
+
+__global__ void prep_scale_kernel(TPrep* prep) {
+    const float mx = __builtin_bit_cast(float, prep->absmax_bits);
+    prep->scale = (mx > 0.0f && mx < __builtin_inff()) ? (double)mx / 1073741824.0 : 0.0;
+}
+
+// planes[p][v][u] (row pitch nq, zero padded), hdiag_int[u], optionally H64[v][u] = scale * integer
+__global__ __launch_bounds__(256) void hquant_kernel(const float* __restrict__ H, int n, int nq, const TPrep* __restrict__ prep,
+                                                    int8_t* __restrict__ planes, int* __restrict__ hdiag_int,
+                                                    double* __restrict__ H64) {
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;  // 4 consecutive u of one row v
+    const int64_t per_row = nq;
+    if (i4 >= (int64_t)n * per_row) return;
+    const int v = (int)(i4 / per_row), u0 = (int)(i4 % per_row);
+    const double scale = prep->scale;
+    const double inv = scale > 0.0 ? 1.0 / scale : 0.0;
+    uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = u0 + k;
+        int xi = 0;
+        if (u < n) {
+            const double x = (double)H[(int64_t)v * n + u] * inv;
+            xi = (int)__builtin_rint(fmin(fmax(x, -1073741824.0), 1073741824.0));
+            if (H64) H64[(int64_t)v * n + u] = scale * (double)xi;
+            if (u == v) hdiag_int[u] = xi;
+        }
+        int r = xi;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {  // balanced base-256 digits: r = d + 256 * r', d in [-128, 127]
+            const int d = ((r + 128) & 255) - 128;
+            r = (r - d) >> 8;
+            pk[p] |= (uint32_t)(d & 255) << (8 * k);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        *reinterpret_cast<uint32_t*>(planes + ((int64_t)p * n + v) * nq + u0) = pk[p];
+}
+
+// bits[(row * ng + g) * 16 + a] : bit l set  <=>  Q[row][64 g + l] == a
+__global__ __launch_bounds__(256) void code_masks_kernel(const uint8_t* __restrict__ Q, int m, int n, int ng,
+                                                        unsigned long long* __restrict__ bits) {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (int64_t)m * ntile) return;
-    const int row = (int)(item / ntile), t = (int)(item % ntile);
-    const int u0 = t * UT;
-    const uint8_t* q = Q + (int64_t)row * n;
-    uint32_t qv[UT / 64];
-#pragma unroll
-    for (int j = 0; j < UT / 64; ++j) {
-        const int u = u0 + 64 * j + lane;
-        qv[j] = u < n ? q[u] : 255u;
-    }
-    uint32_t* out = sorted_off + item * LIST;
-    uint8_t* seg = seg_start + item * 32;
-    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t start = 0;  // in entries, always a multiple of NB
+    if (item >= (int64_t)m * ng) return;
+    const int row = (int)(item / ng), g = (int)(item % ng);
+    const int u = 64 * g + lane;
+    const uint32_t q = u < n ? Q[(int64_t)row * n + u] : 255u;
+    unsigned long long mine = 0;
 #pragma unroll
     for (uint32_t a = 0; a < 16; ++a) {
-        uint32_t pos = start;
-#pragma unroll
-        for (int j = 0; j < UT / 64; ++j) {
-            const uint64_t mk = __ballot(qv[j] == a);
-            if (qv[j] == a) {
-                const uint32_t e = pos + __popcll(mk & lt);
-                out[(e % NB) * 64 + e / NB] = (uint32_t)(64 * j + lane) * (VC * 4);
-            }
-            pos += __popcll(mk);
-        }
-        if (lane == 0) seg[a] = (uint8_t)(start / NB);
-        start = (pos + NB - 1) / NB * NB;
-        if ((uint32_t)lane < start - pos) {  // pad the segment's last batch with the all-zero row
-            const uint32_t e = pos + lane;
-            out[(e % NB) * 64 + e / NB] = ZERO_OFF;
-        }
+        const unsigned long long mk = __ballot(q == a);
+        if ((uint32_t)lane == a) mine = mk;
     }
-    if (lane == 0) seg[16] = (uint8_t)(start / NB);  // <= (256 + 16*7)/8 = 46
+    if (lane < 16) bits[item * 16 + lane] = mine;
 }
 
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void accum_batches(float2& acc, const char* lds_lane, const uint32_t (&off)[NB], int s,
-                                              int e) {
-    for (int b = s; b < e; ++b) {
-        float2 h[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off[j], b);
-            h[j] = *reinterpret_cast<const float2*>(lds_lane + o);
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {  // ascending column order
-            acc.x += h[j].x;
-            acc.y += h[j].y;
-        }
-    }
-}
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __restrict__ planes,
+                                                              const unsigned long long* __restrict__ bits,
+                                                              const uint8_t* __restrict__ Q, int m, int n, int nq, int ng,
+                                                              long long* __restrict__ Mpart) {
+    extern __shared__ __align__(16) char smem[];
+    char* Bbuf = smem;                                                        // 2 x BTILE
+    long long(*Mrow)[RW][256] = reinterpret_cast<long long(*)[RW][256]>(smem + 2 * BTILE);  // [TW][RW][a*16+b]
 
-__global__ __launch_bounds__(TW * 64) void sht_accum_kernel(const float* __restrict__ H, const uint8_t* __restrict__ Q,
-                                                           const uint32_t* __restrict__ sorted_off,
-                                                           const uint8_t* __restrict__ seg_start, int m, int n,
-                                                           int ntile, float* __restrict__ Mws, int kasc) {
-    extern __shared__ __align__(16) char smem[];  // [UT + 1][VC] floats (last row = zeros)
-    float(*Ht)[VC] = reinterpret_cast<float(*)[VC]>(smem);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6;
-    const int c = blockIdx.x;               // v chunk
-    const int rg = blockIdx.y;              // row group
-    const int v0 = c * VC;
-    const int row_base = rg * TR + wv * RW;  // this wave's rows
-    const int t_first = (c * VC) / UT;       // first tile that reaches below the chunk's diagonal
-
-    float2 acc[RW][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n16 = lane & 15, g = lane >> 4;
+    const int nrg = (m + TR - 1) / TR;
+    const int rg = blockIdx.x % nrg, part = blockIdx.x / nrg;
+    const int row0 = rg * TR + wv * RW;
+    int rowc[RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int a = 0; a < 16; ++a) acc[r][a] = make_float2(0.f, 0.f);
+    for (int r = 0; r < RW; ++r) rowc[r] = min(row0 + r, m - 1);
 
-    // global -> register -> LDS staging of one H tile: 256 x 128 floats = 8192 float4, 8 per thread
-    constexpr int NST = (UT * VC / 4) / (TW * 64);
-    float4 stage[NST];
-    auto gload = [&](int t) {
+    for (int i = lane; i < RW * 256; i += 64) Mrow[wv][i >> 8][i & 255] = 0;
+
+    // staging of one digit tile: 4 planes x VCH rows x 256 B = 2048 x 16 B, 4 per thread
+    uint4 stage[4];
+    auto gload = [&](int v0, int t) {
 #pragma unroll
-        for (int e = 0; e < NST; ++e) {
-            const int idx = e * (TW * 64) + tid;
-            const int ul = idx >> 5, v4 = (idx & 31) * 4;
-            const int u = t * UT + ul, v = v0 + v4;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < n) {
-                const float* p = H + (int64_t)u * n + v;
-                if (v + 3 < n && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                    x = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (v + 0 < n) x.x = p[0];
-                    if (v + 1 < n) x.y = p[1];
-                    if (v + 2 < n) x.z = p[2];
-                    if (v + 3 < n) x.w = p[3];
+        for (int e = 0; e < 4; ++e) {
+            const int idx = e * (TW * 64) + tid;  // 0..2047
+            const int c16 = idx & 15, vi = (idx >> 4) & (VCH - 1), p = idx >> 9;
+            const int v = v0 + vi, ub = t * UT + 16 * c16;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (v < n && ub + 15 > v && ub < nq) {
+                x = *reinterpret_cast<const uint4*>(planes + ((int64_t)p * n + v) * nq + ub);
+                if (ub <= v) {  // chunk crosses the diagonal: keep bytes with u > v only
+                    uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int cnt = min(4, max(0, v - (ub + 4 * d) + 1));  // leading bytes to clear
+                        w[d] = cnt >= 4 ? 0u : (w[d] & (0xffffffffu << (8 * cnt)));
+                    }
+                    x = make_uint4(w[0], w[1], w[2], w[3]);
                 }
-                // keep the strict lower triangle u > v only (matters on the tile that crosses the diagonal)
-                if (!(u > v + 0)) x.x = 0.f;
-                if (!(u > v + 1)) x.y = 0.f;
-                if (!(u > v + 2)) x.z = 0.f;
-                if (!(u > v + 3)) x.w = 0.f;
             }
             stage[e] = x;
         }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < NST; ++e) {
+        for (int e = 0; e < 4; ++e) {
             const int idx = e * (TW * 64) + tid;
-            const int ul = idx >> 5, v4 = (idx & 31) * 4;
-            *reinterpret_cast<float4*>(&Ht[ul][v4]) = stage[e];
+            const int c16 = idx & 15, vi = (idx >> 4) & (VCH - 1), p = idx >> 9;
+            *reinterpret_cast<uint4*>(Bbuf + buf * BTILE + (p * VCH + vi) * BROW + 16 * c16) = stage[e];
         }
     };
 
-    if (tid < VC / 4) *reinterpret_cast<float4*>(&Ht[UT][tid * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-    gload(t_first);
-    sstore();
-    __syncthreads();
-    const char* lds_lane = reinterpret_cast<const char*>(&Ht[0][0]) + lane * 8;
-    for (int t = t_first; t < ntile; ++t) {
-        if (t + 1 < ntile) gload(t + 1);
+    const int nchunk = (n + VCH - 1) / VCH;
+    const int ntile = (n + UT - 1) / UT;
+    for (int c = part; c < nchunk; c += NP) {
+        const int v0 = c * VCH;
+        const int t_first = (v0 + 1) / UT;
+        if (t_first >= ntile) continue;
+        v4i acc[RW][2][4];
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const int row = min(row_base + r, m - 1);
-            const int64_t item = (int64_t)row * ntile + t;
-            uint32_t off[NB];
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) off[j] = sorted_off[item * LIST + j * 64 + lane];
-            // segment starts (in batches): 17 bytes, uniform
-            const uint4 s4 = *reinterpret_cast<const uint4*>(seg_start + item * 32);
-            const uint32_t s16 = seg_start[item * 32 + 16];
-            const uint32_t w[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)s4.x),
-                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)s4.y),
-                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)s4.z),
-                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)s4.w)};
-            int st[17];
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int a = 0; a < 16; ++a) st[a] = (int)((w[a >> 2] >> (8 * (a & 3))) & 0xffu);
-            st[16] = (int)__builtin_amdgcn_readfirstlane((int)s16);
+                for (int p = 0; p < 4; ++p) acc[r][nt][p] = (v4i){0, 0, 0, 0};
+
+        __syncthreads();  // previous chunk's last tile fully consumed
+        gload(v0, t_first);
+        sstore(0);
+        __syncthreads();
+        for (int t = t_first; t < ntile; ++t) {
+            const int buf = (t - t_first) & 1;
+            if (t + 1 < ntile) gload(v0, t + 1);
+            // code masks of this wave's rows for the tile's four 64-column steps
+            unsigned long long wbits[RW][4];
 #pragma unroll
-            for (int a = 0; a < 16; ++a) accum_batches(acc[r][a], lds_lane, off, st[a], st[a + 1]);
-        }
-        __syncthreads();  // every wave is done reading the tile
-        if (t + 1 < ntile) {
-            sstore();
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int gi = t * 4 + ks;
+                    wbits[r][ks] = gi < ng ? bits[((int64_t)rowc[r] * ng + gi) * 16 + n16] : 0ull;
+                }
+            const char* Bt = Bbuf + buf * BTILE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (t * UT + ks * 64 + 63 <= v0) continue;  // entirely on or above the diagonal (uniform)
+                v4i bf[2][4];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        bf[nt][p] = *reinterpret_cast<const v4i*>(Bt + (p * VCH + nt * 16 + n16) * BROW + ks * 64 + 16 * g);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const uint32_t b16 = (uint32_t)(wbits[r][ks] >> (16 * g)) & 0xffffu;
+                    v4i af;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) af[d] = (int)((((b16 >> (4 * d)) & 0xfu) * 0x00204081u) & 0x01010101u);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            acc[r][nt][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[nt][p], acc[r][nt][p], 0, 0, 0);
+                }
+            }
+            if (t + 1 < ntile) sstore(buf ^ 1);
             __syncthreads();
         }
+        // bucket the chunk's columns by their code: Mrow[a][b] += sum_p 256^p Y_p[a][v], b = Q[row][v]
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int v = v0 + nt * 16 + n16;
+                const uint32_t b = v < n ? Q[(int64_t)rowc[r] * n + v] : 255u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long long val = (long long)acc[r][nt][0][i] + ((long long)acc[r][nt][1][i] << 8) +
+                                          ((long long)acc[r][nt][2][i] << 16) + ((long long)acc[r][nt][3][i] << 24);
+                    if (b < 16u && val != 0)
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&Mrow[wv][r][(4 * g + i) * 16 + b]),
+                                  (unsigned long long)val);
+                }
+            }
     }
-
-    // ---- epilogue: M_c[row] = Yl[16 codes x 128 v] @ onehot(Q[row, chunk])^T  (16x16x4 fp32 MFMA) ----
-    // per-wave scratch Ys[16][VC + 4] in LDS (the H tile is free after the last barrier)
-    float(*Ys)[VC + 4] = reinterpret_cast<float(*)[VC + 4]>(smem + (size_t)wv * 16 * (VC + 4) * sizeof(float));
-    const int ksub = lane >> 4, c16 = lane & 15;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int row = row_base + r;
-        const int rowc = min(row, m - 1);
-#pragma unroll
-        for (int a = 0; a < 16; ++a) *reinterpret_cast<float2*>(&Ys[a][2 * lane]) = acc[r][a];
-        __builtin_amdgcn_wave_barrier();
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        for (int g = 0; g < VC / 4; ++g) {
-            const int vl = kasc ? (4 * g + ksub) : (4 * g + 3 - ksub);  // accumulate v ascending
-            const int v = v0 + vl;
-            const float av = Ys[c16][vl];
-            const uint32_t qq = (v < n) ? Q[(int64_t)rowc * n + v] : 255u;
-            const float bv = (qq == (uint32_t)c16) ? 1.0f : 0.0f;
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, d, 0, 0, 0);
+    for (int r = 0; r < RW; ++r)
+        if (row0 + r < m) {
+            long long* out = Mpart + ((int64_t)part * m + row0 + r) * 256;
+            for (int i = lane; i < 256; i += 64) out[i] = Mrow[wv][r][i];
         }
-        __builtin_amdgcn_wave_barrier();
-        if (row < m) {
-            float* out = Mws + ((int64_t)c * m + row) * 256;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out[(ksub * 4 + i) * 16 + c16] = d[i];
-        }
-    }
 }
 
-// ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
 // 16 lanes per row, 4 rows per wave, 1 wave per workgroup.
 constexpr int JS = 17;  // padded leading dimension of the fp64 16x16 matrices in LDS
 
@@ -238,13 +261,22 @@ __device__ __forceinline__ double row16_max(double x) {
     x = fmax(x, __shfl_xor(x, 8, 16));
     return x;
 }
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-__global__ __launch_bounds__(64) void solve_kernel(const float* __restrict__ Mws, int nchunk, const float* __restrict__ H,
-                                                   const float* __restrict__ WH, const uint8_t* __restrict__ Q, int m,
-                                                   int n, int V, double rcond, float* __restrict__ T_out,
-                                                   float* __restrict__ A_out, float* __restrict__ b_out) {
+template <typename WHT>
+__global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict__ Mpart, const TPrep* __restrict__ prep,
+                                                     const int* __restrict__ hdiag_int, const WHT* __restrict__ WH,
+                                                     const double* __restrict__ wHw, const uint8_t* __restrict__ Q, int m,
+                                                     int n, int V, double rcond, float* __restrict__ T_out,
+                                                     float* __restrict__ A_out, float* __restrict__ b_out,
+                                                     double* __restrict__ loss_rows) {
     __shared__ double As[4][16][JS];
     __shared__ double Es[4][16][JS];
+    __shared__ double A0[4][16][JS];       // unrounded A (for the loss), also scratch for the bucket sums
+    __shared__ long long Di[4][16][JS];    // lane-private integer buckets of diag(H), then scratch for the transpose
     __shared__ double CS[4][8][2];
     __shared__ double Coef[4][16];
 
@@ -254,47 +286,62 @@ __global__ __launch_bounds__(64) void solve_kernel(const float* __restrict__ Mws
     const int rowc = min(row, m - 1);
     double(*A)[JS] = As[rs];
     double(*E)[JS] = Es[rs];
+    double(*B0)[JS] = A0[rs];
+    const double scale = prep->scale;
 
-    // ---- assemble: lane l owns column l of M (summed over chunks in ascending order) ----
-    {
-        float col[16];
-#pragma unroll
-        for (int a = 0; a < 16; ++a) col[a] = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            const float* src = Mws + ((int64_t)c * m + rowc) * 256;
-#pragma unroll
-            for (int a = 0; a < 16; ++a) col[a] += src[a * 16 + l];
-        }
-#pragma unroll
-        for (int a = 0; a < 16; ++a) A[a][l] = (double)col[a];
-    }
-    // lane l == code l: diagonal term and right-hand side, ascending u
-    double dsum = 0.0, bsum = 0.0;
-    {
-        const uint8_t* q = Q + (int64_t)rowc * n;
-        const float* wh = WH + (int64_t)rowc * n;
-        for (int u = 0; u < n; ++u) {
-            const bool hit = (q[u] == (uint8_t)l);
-            const double hd = (double)H[(int64_t)u * n + u];
-            const double wv = (double)wh[u];
-            dsum += hit ? hd : 0.0;
-            bsum += hit ? wv : 0.0;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // A = M + M^T + diag, rounded to fp32 (the reference holds A and b in fp32), exactly symmetric
-    double colA[16];
+    // ---- b_i[a] = sum_{u in a} WH[row][u] and D[a] = sum_{u in a} H[u][u]: lane l takes u = 16 t + l into its own
+    //      16 buckets (no atomics), then lane a sums bucket a over the lanes in fixed order
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-        double x = A[a][l] + A[l][a];
-        if (a == l) x += dsum;
-        colA[a] = (double)(float)x;
+        B0[l][a] = 0.0;
+        Di[rs][l][a] = 0;
     }
+    {
+        const uint8_t* q = Q + (int64_t)rowc * n;
+        const WHT* wh = WH + (int64_t)rowc * n;
+        for (int u = l; u < n; u += 16) {
+            const int a = min((int)q[u], 15);
+            B0[l][a] += (double)wh[u];
+            Di[rs][l][a] += (long long)hdiag_int[u];
+        }
+    }
+    wave_sync();
+    double bsum = 0.0;
+    long long dsum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        bsum += B0[k][l];
+        dsum += Di[rs][k][l];
+    }
+    wave_sync();
+
+    // ---- A = M + M^T + diag  (exact integers), lane l owns column l ----
+    long long col[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) col[a] = 0;
+    for (int p = 0; p < NP; ++p) {
+        const long long* src = Mpart + ((int64_t)p * m + rowc) * 256;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) col[a] += src[a * 16 + l];
+    }
+#pragma unroll
+    for (int a = 0; a < 16; ++a) Di[rs][a][l] = col[a];
+    wave_sync();
+    double colA[16], colA0[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        long long x = Di[rs][a][l] + Di[rs][l][a];
+        if (a == l) x += dsum;
+        colA0[a] = scale * (double)x;
+        colA[a] = (double)(float)colA0[a];  // the reference holds A and b in fp32
+    }
+    const double bl0 = bsum;
     const double bl = (double)(float)bsum;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         A[a][l] = colA[a];
+        B0[a][l] = colA0[a];
         E[a][l] = (a == l) ? 1.0 : 0.0;
     }
     if (row < m) {
@@ -302,7 +349,7 @@ __global__ __launch_bounds__(64) void solve_kernel(const float* __restrict__ Mws
             for (int a = 0; a < V; ++a) A_out[((int64_t)row * V + a) * V + l] = (float)colA[a];
         if (b_out && l < V) b_out[(int64_t)row * V + l] = (float)bl;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
 
     // ---- round-robin Jacobi: 15 rounds of 8 disjoint rotations per sweep ----
     const int t = l >> 1;  // pair handled (redundantly) by lanes 2t, 2t+1
@@ -339,7 +386,7 @@ __global__ __launch_bounds__(64) void solve_kernel(const float* __restrict__ Mws
                 CS[rs][t][0] = cc;
                 CS[rs][t][1] = ss;
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
             // column phase: lane l rotates row l's entries (p_i, q_i) for all 8 pairs
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -356,7 +403,7 @@ __global__ __launch_bounds__(64) void solve_kernel(const float* __restrict__ Mws
                 E[l][pi] = ci * ekp - si * ekq;
                 E[l][qi] = si * ekp + ci * ekq;
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
             // row phase: lane l rotates column l's entries of rows (p_i, q_i)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -370,7 +417,7 @@ __global__ __launch_bounds__(64) void solve_kernel(const float* __restrict__ Mws
                 A[pi][l] = ci * apk - si * aqk;
                 A[qi][l] = si * apk + ci * aqk;
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
         }
     }
 
@@ -378,48 +425,231 @@ __global__ __launch_bounds__(64) void solve_kernel(const float* __restrict__ Mws
     const double lam = A[l][l];
     const double lmax = row16_max(fabs(lam));
     Coef[rs][l] = bl;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     double proj = 0.0;
 #pragma unroll
     for (int a = 0; a < 16; ++a) proj += E[a][l] * Coef[rs][a];
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     const bool keep = fabs(lam) > rcond * lmax;
     Coef[rs][l] = keep ? proj / lam : 0.0;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     double x = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) x += E[l][k] * Coef[rs][k];
-    if (row < m && l < V) T_out[(int64_t)row * V + l] = (float)x;
+    const float tl = (float)x;
+    if (row < m && l < V) T_out[(int64_t)row * V + l] = tl;
+
+    // ---- loss of this row with the NEW codebook: w^T H w - 2 t^T b + t^T A t (fp64, unrounded A and b) ----
+    if (loss_rows) {
+        const double td = (l < V) ? (double)tl : 0.0;
+        wave_sync();
+        Coef[rs][l] = td;
+        wave_sync();
+        double at = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) at += B0[l][k] * Coef[rs][k];  // (A t)_l, A symmetric
+        const double term = row16_sum(td * at - 2.0 * td * bl0);
+        if (row < m && l == 0) loss_rows[row] = wHw[row] + term;
+    }
+}
+
+// w_i^T (W H)_i per row, fixed order
+__global__ __launch_bounds__(256) void whw_kernel(const float* __restrict__ W, const double* __restrict__ WH64, int m, int n,
+                                                 double* __restrict__ wHw) {
+    __shared__ double sh[256];
+    const int row = blockIdx.x;
+    double s = 0.0;
+    for (int u = threadIdx.x; u < n; u += 256) s += (double)W[(int64_t)row * n + u] * WH64[(int64_t)row * n + u];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wHw[row] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void sum_rows_kernel(const double* __restrict__ rows, int m, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < m; i += 256) s += rows[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp64 GEMM C[M,N] = A[M,K] (fp32, widened on load) @ B[K,N] (fp64) on v_mfma_f64_16x16x4_f64; used once per layer
+// for W @ H_fixed.  64x64 tile, 4 waves x (2x2 tiles of 16x16), K slabs of 16 through LDS.
+constexpr int DM = 64, DN = 64, DK = 16;
+
+__global__ __launch_bounds__(256) void gemm_f64_kernel(const float* __restrict__ A, const double* __restrict__ B,
+                                                      double* __restrict__ C, int M, int N, int K) {
+    __shared__ double As[DK][DM + 2];
+    __shared__ double Bs[DK][DN + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_n = (N + DN - 1) / DN;
+    const int bm = (blockIdx.x / tiles_n) * DM, bn = (blockIdx.x % tiles_n) * DN;
+    const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += DK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // A slab 64 x 16, B slab 16 x 64: 1024 elements each, 4 per thread
+            const int idx = e * 256 + tid;
+            const int ar = idx >> 4, ak = idx & 15;
+            const int row = bm + ar, k = k0 + ak;
+            As[ak][ar] = (row < M && k < K) ? (double)A[(int64_t)row * K + k] : 0.0;
+            const int bk = idx >> 6, bc = idx & 63;
+            const int kk = k0 + bk, col = bn + bc;
+            Bs[bk][bc] = (kk < K && col < N) ? B[(int64_t)kk * N + col] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < DK; kk += 4) {
+            const int kq = kk + (lane >> 4);
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[kq][wm + 16 * i + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[kq][wn + 16 * j + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bm + wm + 16 * i + (lane >> 4) + 4 * r;
+                const int col = bn + wn + 16 * j + (lane & 15);
+                if (row < M && col < N) C[(int64_t)row * N + col] = acc[i][j][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
+    TLayout lo;
+    lo.nq = (n + UT - 1) / UT * UT;
+    lo.ng = (n + 63) / 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    lo.off_prep = take(sizeof(TPrep));
+    lo.off_planes = take((size_t)4 * n * lo.nq);
+    lo.off_hdiag = take((size_t)n * sizeof(int));
+    lo.off_bits = take((size_t)m * lo.ng * 16 * sizeof(unsigned long long));
+    lo.off_mpart = take((size_t)NP * m * 256 * sizeof(long long));
+    lo.off_h64 = lo.off_wh64 = lo.off_whw = lo.off_lossrows = 0;
+    if (with_f64) {
+        lo.off_h64 = take((size_t)n * n * sizeof(double));
+        lo.off_wh64 = take((size_t)m * n * sizeof(double));
+        lo.off_whw = take((size_t)m * sizeof(double));
+        lo.off_lossrows = take((size_t)m * sizeof(double));
+    }
+    lo.total = off;
+    return lo;
+}
+
+// once per layer: fixed-point planes of H (+ optionally W @ H_fixed in fp64 and w^T H w per row)
+int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayout& lo, char* ws, bool with_f64,
+              hipStream_t stream) {
+    TPrep* prep = reinterpret_cast<TPrep*>(ws + lo.off_prep);
+    int8_t* planes = reinterpret_cast<int8_t*>(ws + lo.off_planes);
+    int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
+    double* H64 = with_f64 ? reinterpret_cast<double*>(ws + lo.off_h64) : nullptr;
+    ProfScope prof(KID_T_PREP, stream);
+    GANQ_HIP_CHECK(hipMemsetAsync(prep, 0, sizeof(TPrep), stream));
+    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, stream, H, n * n, prep);
+    hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(1), 0, stream, prep);
+    const int64_t quads = n * lo.nq / 4;
+    hipLaunchKernelGGL(hquant_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, H, (int)n, (int)lo.nq, prep,
+                       planes, hdiag, H64);
+    GANQ_LAUNCH_CHECK();
+    if (with_f64) {
+        double* WH64 = reinterpret_cast<double*>(ws + lo.off_wh64);
+        double* wHw = reinterpret_cast<double*>(ws + lo.off_whw);
+        const int tiles = (int)(((m + DM - 1) / DM) * ((n + DN - 1) / DN));
+        hipLaunchKernelGGL(gemm_f64_kernel, dim3(tiles), dim3(256), 0, stream, W, H64, WH64, (int)m, (int)n, (int)n);
+        hipLaunchKernelGGL(whw_kernel, dim3((unsigned)m), dim3(256), 0, stream, W, WH64, (int)m, (int)n, wHw);
+        GANQ_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// per iteration: masks -> integer accumulation -> per-row solve (+ loss rows)
+int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
+              float* T_out, float* A_out, float* b_out, double* loss_out, hipStream_t stream) {
+    TPrep* prep = reinterpret_cast<TPrep*>(ws + lo.off_prep);
+    int8_t* planes = reinterpret_cast<int8_t*>(ws + lo.off_planes);
+    int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws + lo.off_bits);
+    long long* mpart = reinterpret_cast<long long*>(ws + lo.off_mpart);
+    {
+        ProfScope prof(KID_SORT_CODES, stream);
+        const int64_t items = m * lo.ng;
+        hipLaunchKernelGGL(code_masks_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, Q, (int)m, (int)n,
+                           (int)lo.ng, bits);
+    }
+    GANQ_LAUNCH_CHECK();
+    static bool attr_set = false;
+    const size_t smem = 2 * (size_t)BTILE + (size_t)TW * RW * 256 * sizeof(long long);
+    if (!attr_set) {
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(onehot_accum_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    {
+        ProfScope prof(KID_SHT_ACCUM, stream);
+        const int nrg = (int)((m + TR - 1) / TR);
+        hipLaunchKernelGGL(onehot_accum_kernel, dim3((unsigned)(nrg * NP)), dim3(TW * 64), smem, stream, planes, bits, Q, (int)m,
+                           (int)n, (int)lo.nq, (int)lo.ng, mpart);
+    }
+    GANQ_LAUNCH_CHECK();
+    {
+        ProfScope prof(KID_T_SOLVE, stream);
+        const dim3 grid((unsigned)((m + 3) / 4));
+        if (WH32) {
+            hipLaunchKernelGGL(t_solve_kernel<float>, grid, dim3(64), 0, stream, mpart, prep, hdiag, WH32,
+                               static_cast<const double*>(nullptr), Q, (int)m, (int)n, V, rcond, T_out, A_out, b_out,
+                               static_cast<double*>(nullptr));
+        } else {
+            const double* WH64 = reinterpret_cast<const double*>(ws + lo.off_wh64);
+            const double* wHw = reinterpret_cast<const double*>(ws + lo.off_whw);
+            double* loss_rows = reinterpret_cast<double*>(ws + lo.off_lossrows);
+            hipLaunchKernelGGL(t_solve_kernel<double>, grid, dim3(64), 0, stream, mpart, prep, hdiag, WH64, wHw, Q, (int)m,
+                               (int)n, V, rcond, T_out, A_out, b_out, loss_out ? loss_rows : nullptr);
+            if (loss_out) hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, loss_rows, (int)m, loss_out);
+        }
+    }
+    GANQ_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace ganq
 
 using namespace ganq;
 
-struct UpdateTLayout {
-    int64_t ntile, nchunk;
-    size_t off_sorted, off_seg, off_mws, total;
-};
-
-static UpdateTLayout update_t_layout(int64_t m, int64_t n) {
-    UpdateTLayout lo;
-    lo.ntile = (n + UT - 1) / UT;
-    lo.nchunk = (n + VC - 1) / VC;
-    size_t off = 0;
-    lo.off_sorted = off;
-    off = align_up(off + (size_t)m * (size_t)lo.ntile * LIST * sizeof(uint32_t), 256);
-    lo.off_seg = off;
-    off = align_up(off + (size_t)m * (size_t)lo.ntile * 32, 256);
-    lo.off_mws = off;
-    off = align_up(off + (size_t)lo.nchunk * (size_t)m * 256 * sizeof(float), 256);
-    lo.total = off;
-    return lo;
-}
-
 extern "C" size_t ganq_update_t_workspace_bytes(int64_t m, int64_t n, int V) {
     (void)V;
     if (m <= 0 || n <= 0) return 0;
-    return update_t_layout(m, n).total;
+    return t_layout(m, n, false).total;
 }
 
 extern "C" int ganq_update_t(const float* WH, const float* H, const uint8_t* Q, int64_t m, int64_t n, int V,
@@ -430,46 +660,13 @@ extern "C" int ganq_update_t(const float* WH, const float* H, const uint8_t* Q, 
     if (V < 2 || V > 16) return fail(-2, "ganq_update_t: V=%d not supported (bits 2..4 are implemented)", V);
     if (m > INT32_MAX / 2 || n > INT32_MAX / 2) return fail(-1, "ganq_update_t: shape too large");
     if (!WH || !H || !Q || !T_out) return fail(-3, "ganq_update_t: null pointer");
-    const UpdateTLayout lo = update_t_layout(m, n);
-    const int64_t ntile = lo.ntile, nchunk = lo.nchunk;
+    const TLayout lo = t_layout(m, n, false);
     if (!workspace || workspace_bytes < lo.total)
         return fail(-4, "ganq_update_t: workspace %zu B < required %zu B", workspace_bytes, lo.total);
     if (rcond < 0) rcond = 1.1920928955078125e-07 * (double)V;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    int rc = ganq_hip_selftest(stream_);
-    if (rc) return rc;
     char* ws = static_cast<char*>(workspace);
-    uint32_t* sorted_off = reinterpret_cast<uint32_t*>(ws + lo.off_sorted);
-    uint8_t* seg = reinterpret_cast<uint8_t*>(ws + lo.off_seg);
-    float* mws = reinterpret_cast<float*>(ws + lo.off_mws);
-
-    const int64_t items = m * ntile;
-    {
-        ProfScope prof(KID_SORT_CODES, stream);
-        hipLaunchKernelGGL(sort_codes_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, Q, (int)m, (int)n,
-                           (int)ntile, sorted_off, seg);
-    }
-    GANQ_LAUNCH_CHECK();
-
-    static bool attr_set = false;
-    const size_t smem = ACCUM_SMEM;
-    if (!attr_set) {
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sht_accum_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
-    const dim3 grid((unsigned)nchunk, (unsigned)((m + TR - 1) / TR));
-    {
-        ProfScope prof(KID_SHT_ACCUM, stream);
-        hipLaunchKernelGGL(sht_accum_kernel, grid, dim3(TW * 64), smem, stream, H, Q, sorted_off, seg, (int)m, (int)n,
-                           (int)ntile, mws, mfma_k_ascending());
-    }
-    GANQ_LAUNCH_CHECK();
-    {
-        ProfScope prof(KID_T_SOLVE, stream);
-        hipLaunchKernelGGL(solve_kernel, dim3((unsigned)((m + 3) / 4)), dim3(64), 0, stream, mws, (int)nchunk, H, WH, Q,
-                           (int)m, (int)n, V, rcond, T_out, A_out, b_out);
-    }
-    GANQ_LAUNCH_CHECK();
-    return 0;
+    int rc = t_prepare(nullptr, H, m, n, lo, ws, false, stream);
+    if (rc) return rc;
+    return t_iterate(Q, m, n, V, rcond, lo, ws, WH, T_out, A_out, b_out, nullptr, stream);
 }
