@@ -30,6 +30,7 @@ SIGNATURES = {
     "ganq_hip_version": (ctypes.c_int, []),
     "ganq_hip_last_error": (ctypes.c_char_p, []),
     "ganq_hip_selftest": (ctypes.c_int, [_c_vp]),
+    "ganq_debug_div_check": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _c_vp, _c_vp, _c_vp]),
     "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ganq_kmeans_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
     "ganq_kmeans_init": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
@@ -131,6 +132,15 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def selftest():
     _check(lib().ganq_hip_selftest(_stream()), "ganq_hip_selftest")
+
+
+def debug_div_check(count: int, seed: int = 1):
+    """(mismatches, (a, b)) of the reciprocal-based quotient vs IEEE division over `count` pseudo-random pairs"""
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    first = torch.zeros(2, dtype=torch.float32, device="cuda")
+    _check(lib().ganq_debug_div_check(int(count), int(seed), bad.data_ptr(), first.data_ptr(), _stream()),
+           "ganq_debug_div_check")
+    return int(bad), tuple(first.tolist())
 
 
 def solve_s(W, L, T, want_err=False):

@@ -39,9 +39,50 @@ __global__ void probe_mfma_kernel(const float* __restrict__ A, const float* __re
     for (int r = 0; r < 4; ++r) D[((l >> 4) * 4 + r) * 16 + (l & 15)] = d[r];
 }
 
+// Brute-force check of the division shortcut used by the S-solve: with rinv = RN(1/b),
+//     q0 = RN(a * rinv);  e = fma(-q0, b, a);  q = fma(e, rinv, q0)
+// must equal the IEEE quotient RN(a / b) (Markstein).  Counts disagreements over pseudo-random operands drawn from
+// the ranges the solve sees (|a| small residuals incl. tiny values, b = Cholesky diagonal > 0).
+__global__ __launch_bounds__(256) void div_check_kernel(uint64_t count, uint32_t seed, unsigned long long* mismatches,
+                                                        float* first_bad) {
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        uint64_t x = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; x *= 0x94D049BB133111EBull; x ^= x >> 29;
+        const uint32_t ma = (uint32_t)x & 0x007fffffu, mb = (uint32_t)(x >> 23) & 0x007fffffu;
+        const uint32_t ea = 127u - 40u + (uint32_t)((x >> 46) % 48u);   // 2^-40 .. 2^7
+        const uint32_t eb = 127u - 12u + (uint32_t)((x >> 52) % 24u);   // 2^-12 .. 2^11
+        const uint32_t sa = (uint32_t)(x >> 63) << 31;
+        const float a = __builtin_bit_cast(float, sa | (ea << 23) | ma);
+        const float b = __builtin_bit_cast(float, (eb << 23) | mb);
+        const float rinv = 1.0f / b;
+        const float q0 = a * rinv;
+        const float e = fmaf(-q0, b, a);
+        const float q = fmaf(e, rinv, q0);
+        const float ref = a / b;
+        if (__builtin_bit_cast(uint32_t, q) != __builtin_bit_cast(uint32_t, ref)) {
+            if (bad == 0 && atomicAdd(mismatches, 0ull) == 0) {
+                first_bad[0] = a;
+                first_bad[1] = b;
+            }
+            ++bad;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace ganq
 
 using namespace ganq;
+
+extern "C" int ganq_debug_div_check(uint64_t count, uint32_t seed, unsigned long long* mismatches_dev, float* first_bad_dev,
+                                    void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    GANQ_HIP_CHECK(hipMemsetAsync(mismatches_dev, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(div_check_kernel, dim3(4096), dim3(256), 0, stream, count, seed, mismatches_dev, first_bad_dev);
+    GANQ_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ganq_hip_version(void) { return GANQ_HIP_ABI_VERSION; }
 

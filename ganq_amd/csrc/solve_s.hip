@@ -58,10 +58,15 @@ struct PanelState {
 
 // One column step.  JJ = column inside the panel; its owner is lane (JJ & 15) of each DPP row, register JJ >> 4.
 template <int JJ>
-__device__ __forceinline__ void panel_step(PanelState& st, const float4 (*Ld)[16]) {
+__device__ __forceinline__ void panel_step(PanelState& st, const float4 (*Ld)[16], const float2* Dg) {
     constexpr int KREG = JJ >> 4, OWN = JJ & 15;
-    const float ljj = reinterpret_cast<const float*>(&Ld[JJ][OWN])[KREG];  // L[j][j], uniform LDS read
-    const float quo = st.r[KREG] / ljj;                                    // IEEE fp32 division
+    // r / L[j][j] as an exactly rounded quotient without the division sequence (Markstein): rinv = RN(1/L[j][j]) is
+    // computed once per column with a true division; q0 = RN(r*rinv); e = fma(-q0, L, r) is exact; RN(q0 + e*rinv) is
+    // the IEEE quotient (checked against the division by ganq_debug_div_check and, end to end, by the oracle tests)
+    const float2 dg = Dg[JJ];  // {L[j][j], RN(1 / L[j][j])}, uniform LDS read
+    const float q0 = st.r[KREG] * dg.y;
+    const float qe = fmaf(-q0, dg.x, st.r[KREG]);
+    const float quo = fmaf(qe, dg.y, q0);
     const float eff_l = st.w[KREG] + quo;
     const float eff = dpp_f<0x150 + OWN>(eff_l);  // row_newbcast: owner lane -> its 16-lane row
     const float wj = dpp_f<0x150 + OWN>(st.w[KREG]);
@@ -83,13 +88,13 @@ __device__ __forceinline__ void panel_step(PanelState& st, const float4 (*Ld)[16
 }
 
 template <bool FULL, int... I>
-__device__ __forceinline__ void panel_all(PanelState& st, const float4 (*Ld)[16], int wd,
+__device__ __forceinline__ void panel_all(PanelState& st, const float4 (*Ld)[16], const float2* Dg, int wd,
                                           std::integer_sequence<int, I...>) {
     // steps run from the panel's last column down to its first
     if constexpr (FULL) {
-        (panel_step<SB - 1 - I>(st, Ld), ...);
+        (panel_step<SB - 1 - I>(st, Ld, Dg), ...);
     } else {
-        ((SB - 1 - I < wd ? panel_step<SB - 1 - I>(st, Ld) : (void)0), ...);
+        ((SB - 1 - I < wd ? panel_step<SB - 1 - I>(st, Ld, Dg) : (void)0), ...);
     }
 }
 
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(256) void solve_s_kernel(const float* __restrict__ 
                                                       float* __restrict__ ErrT) {
     __shared__ float4 Ld[SB][16];      // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
     __shared__ float Rp[SR][SB + 4];   // residual panel handed from (G) to (P)
+    __shared__ float2 Dg[SB];          // {L[j][j], 1 / L[j][j]} of the panel's columns
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -130,6 +136,10 @@ __global__ __launch_bounds__(256) void solve_s_kernel(const float* __restrict__ 
             if (jj < wd && col < wd) v = L[(int64_t)(j0 + jj) * ldl + j0 + col];
             reinterpret_cast<float*>(&Ld[jj][col & 15])[col >> 4] = v;
         }
+        if (tid < SB) {
+            const float d = (tid < wd) ? L[(int64_t)(j0 + tid) * ldl + j0 + tid] : 1.0f;
+            Dg[tid] = make_float2(d, 1.0f / d);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int col = c16 + 16 * k;
@@ -139,39 +149,58 @@ __global__ __launch_bounds__(256) void solve_s_kernel(const float* __restrict__ 
         }
 
         // ---- (G) residual GEMM: wave wv -> panel columns 16wv..16wv+15, all 16 rows -----------------
+        // k-group g covers columns 4g..4g+3; inside one MFMA the slice order follows the probed k order so that
+        // the chain always runs over columns in descending order.  Addresses are (uniform base) + (per-lane
+        // 32-bit offset): scalar pointer arithmetic, one VMEM instruction per operand.
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         {
-            const int gbot = (j0 + SB) >> 2;  // k-group g covers columns 4g..4g+3
-            const int gtop = (n - 1) >> 2;
-            const int ngroups = gtop - gbot + 1;  // <= 0 for the last panel
+            const int gbot = (j0 + SB) >> 2;
             const int ksub = lane >> 4;
-            const int colB = j0 + 16 * wv + c16;  // < n whenever ngroups > 0 (only the last panel is partial)
-            auto load_group = [&](int gi, float& a, float& bb) {
-                // gi counts groups from the top; slice order inside the MFMA follows the probed k order
-                const int g = gtop - gi;
-                const int u = KASC ? (4 * g + 3 - ksub) : (4 * g + ksub);
-                const bool ok = (gi < ngroups) && (u < n);
+            const int kslot = KASC ? (3 - ksub) : ksub;  // column inside the group handled by this lane's slice
+            const int colB = j0 + 16 * wv + c16;         // < n whenever there is any group (only the last panel is partial)
+            if ((n & 3) && (n >> 2) >= gbot) {           // ragged top group: columns >= n contribute nothing
+                const int u = 4 * (n >> 2) + kslot;
+                const bool ok = u < n;
                 const int uu = ok ? u : (n - 1);
                 const float av = errt[(int64_t)uu * SR + c16];
-                const float bv = L[(int64_t)uu * ldl + (ok ? colB : 0)];
-                a = ok ? av : 0.0f;
-                bb = ok ? bv : 0.0f;
+                const float bv = L[(int64_t)uu * ldl + colB];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? av : 0.0f, ok ? bv : 0.0f, acc, 0, 0, 0);
+            }
+            const int gtop = (n >> 2) - 1;               // highest full group
+            const int nfull = gtop - gbot + 1;           // <= 0 for the last panel
+            const uint32_t laneA = (uint32_t)(kslot * SR + c16);
+            const uint32_t laneB = (uint32_t)kslot * (uint32_t)ldl + (uint32_t)colB;
+            auto load_batch = [&](int g0, float (&a)[SPF], float (&bb)[SPF]) {  // groups g0, g0-1, .., g0-SPF+1
+#pragma unroll
+                for (int i = 0; i < SPF; ++i) {
+                    const float* __restrict__ Ag = errt + (int64_t)(g0 - i) * (4 * SR);
+                    const float* __restrict__ Bg = L + (int64_t)(g0 - i) * 4 * ldl;
+                    a[i] = Ag[laneA];
+                    bb[i] = Bg[laneB];
+                }
             };
             float a0[SPF], b0[SPF], a1[SPF], b1[SPF];
-            if (ngroups > 0) {
-#pragma unroll
-                for (int i = 0; i < SPF; ++i) load_group(i, a0[i], b0[i]);
-                for (int base = 0; base < ngroups; base += 2 * SPF) {
-#pragma unroll
-                    for (int i = 0; i < SPF; ++i) load_group(base + SPF + i, a1[i], b1[i]);
+            int g = gtop;
+            int nbatch = nfull > 0 ? nfull / SPF : 0;
+            if (nbatch > 0) {
+                load_batch(g, a0, b0);
+                while (true) {
+                    if (nbatch > 1) load_batch(g - SPF, a1, b1);
 #pragma unroll
                     for (int i = 0; i < SPF; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[i], acc, 0, 0, 0);
-                    if (base + SPF >= ngroups) break;
-#pragma unroll
-                    for (int i = 0; i < SPF; ++i) load_group(base + 2 * SPF + i, a0[i], b0[i]);
+                    g -= SPF;
+                    if (--nbatch == 0) break;
+                    if (nbatch > 1) load_batch(g - SPF, a0, b0);
 #pragma unroll
                     for (int i = 0; i < SPF; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], b1[i], acc, 0, 0, 0);
+                    g -= SPF;
+                    if (--nbatch == 0) break;
                 }
+            }
+            for (; g >= gbot; --g) {  // fewer than SPF groups left
+                const float* __restrict__ Ag = errt + (int64_t)g * (4 * SR);
+                const float* __restrict__ Bg = L + (int64_t)g * 4 * ldl;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ag[laneA], Bg[laneB], acc, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -182,9 +211,9 @@ __global__ __launch_bounds__(256) void solve_s_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) st.r[k] = Rp[prow_in_tile][c16 + 16 * k];
         if (wd == SB) {
-            panel_all<true>(st, Ld, wd, std::make_integer_sequence<int, SB>{});
+            panel_all<true>(st, Ld, Dg, wd, std::make_integer_sequence<int, SB>{});
         } else {
-            panel_all<false>(st, Ld, wd, std::make_integer_sequence<int, SB>{});
+            panel_all<false>(st, Ld, Dg, wd, std::make_integer_sequence<int, SB>{});
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -44,6 +44,11 @@ const char* ganq_hip_last_error(void);
  * Returns 0 and caches the result; the compute entry points call it lazily. */
 int ganq_hip_selftest(void* stream);
 
+/* Developer check (tests): counts operand pairs for which the S-solve's reciprocal-based quotient differs from the IEEE
+ * division; mismatches_dev: one uint64 on the device, first_bad_dev: two floats (a, b) of one offending pair. */
+int ganq_debug_div_check(uint64_t count, uint32_t seed, unsigned long long* mismatches_dev, float* first_bad_dev,
+                         void* stream);
+
 /* ---- a1: Hessian accumulation (gptq.py:96-131 process_batch) --------------------------------
  * One calibration batch: X [rows, n] fp16 or bf16 (dtype: 0 = fp16, 1 = bf16), `batch` = number
  * of sequences in it (gptq.py:104), nsamples_before = sequences accumulated so far.

@@ -224,3 +224,9 @@ def test_run_layer_vs_oracle(hip, oracle, m, n, V, K, seed):
     frac = float((Q.cpu().numpy() != Qo).mean())
     assert frac < 1e-3, f"index mismatch fraction {frac}"
     assert rel_fro(T.cpu().numpy(), To) < 1e-3 if frac > 0 else rel_fro(T.cpu().numpy(), To) < TOL_T
+
+
+def test_reciprocal_quotient_equals_ieee_division(hip):
+    # the S-solve replaces r / L[j][j] by a reciprocal-based sequence that must round like the division
+    bad, first = hip.debug_div_check(1 << 30, seed=7)
+    assert bad == 0, f"{bad} of 2^30 quotients differ from IEEE division, e.g. a,b = {first}"
