@@ -18,6 +18,8 @@
 // The per-row 16x16 systems are then solved in fp64 (round-robin Jacobi, gelsd cut-off); with A exact and
 // b = S (W H) accumulated in fp64 the closed-form loss has no cancellation problem, so no (W-Wq)@H product is
 // needed per iteration.
+#include <cstdlib>
+
 #include "common.h"
 #include "update_t.h"
 
@@ -33,6 +35,7 @@ constexpr int BROW = UT + 16;   // LDS row pitch of a digit tile in bytes (pad a
 constexpr int BTILE = 4 * VCH * BROW;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct TPrep {              // device-side header written by t_prepare
@@ -111,19 +114,26 @@ __global__ __launch_bounds__(256) void code_masks_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __restrict__ planes,
                                                               const unsigned long long* __restrict__ bits,
                                                               const uint8_t* __restrict__ Q, int m, int n, int nq, int ng,
-                                                              long long* __restrict__ Mpart) {
+                                                              long long* __restrict__ Mpart, long long* __restrict__ stamps) {
     extern __shared__ __align__(16) char smem[];
+    long long st_pro = 0, st_loop = 0, st_flush = 0, st_t0 = 0;
     char* Bbuf = smem;                                                        // 2 x BTILE
     long long(*Mrow)[RW][256] = reinterpret_cast<long long(*)[RW][256]>(smem + 2 * BTILE);  // [TW][RW][a*16+b]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n16 = lane & 15, g = lane >> 4;
+    // v_mfma_i32_32x32x32_i8: A rows = (row of the pair, code), 32 u per instruction, B columns = the chunk's 32 v.
+    // lane l: A row / B column i32 = l & 31, k bytes 16*(l >> 5) .. +15
+    const int i32 = lane & 31, kb = lane >> 5;
+    const int r2 = i32 >> 4, a16 = i32 & 15;
     const int nrg = (m + TR - 1) / TR;
     const int rg = blockIdx.x % nrg, part = blockIdx.x / nrg;
     const int row0 = rg * TR + wv * RW;
     int rowc[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) rowc[r] = min(row0 + r, m - 1);
+    int mrow[RW / 2];  // the row whose masks this lane expands, per row pair
+#pragma unroll
+    for (int p = 0; p < RW / 2; ++p) mrow[p] = min(row0 + 2 * p + r2, m - 1);
 
     for (int i = lane; i < RW * 256; i += 64) Mrow[wv][i >> 8][i & 255] = 0;
 
@@ -166,73 +176,87 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
         const int v0 = c * VCH;
         const int t_first = (v0 + 1) / UT;
         if (t_first >= ntile) continue;
-        v4i acc[RW][2][4];
+        v16i acc[RW / 2][4];
 #pragma unroll
-        for (int r = 0; r < RW; ++r)
+        for (int p = 0; p < RW / 2; ++p)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int d = 0; d < 4; ++d)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) acc[r][nt][p] = (v4i){0, 0, 0, 0};
+                for (int r = 0; r < 16; ++r) acc[p][d][r] = 0;
 
+        st_t0 = __builtin_amdgcn_s_memtime();
         __syncthreads();  // previous chunk's last tile fully consumed
         gload(v0, t_first);
         sstore(0);
         __syncthreads();
+        // code masks of this lane's (row, code), one 64-column step ahead of their use
+        unsigned long long wb[2][RW / 2];
+        auto load_masks = [&](int gi, unsigned long long (&dst)[RW / 2]) {
+#pragma unroll
+            for (int p = 0; p < RW / 2; ++p) dst[p] = gi < ng ? bits[((int64_t)mrow[p] * ng + gi) * 16 + a16] : 0ull;
+        };
+        load_masks(t_first * 4, wb[0]);
+        { const long long tt = __builtin_amdgcn_s_memtime(); st_pro += tt - st_t0; st_t0 = tt; }
         for (int t = t_first; t < ntile; ++t) {
             const int buf = (t - t_first) & 1;
             if (t + 1 < ntile) gload(v0, t + 1);
-            // code masks of this wave's rows for the tile's four 64-column steps
-            unsigned long long wbits[RW][4];
+            const char* Bt = Bbuf + buf * BTILE + i32 * BROW + 16 * kb;
+            auto read_b = [&](int ks, int kh, v4i (&bf)[4]) {
 #pragma unroll
-            for (int r = 0; r < RW; ++r)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int gi = t * 4 + ks;
-                    wbits[r][ks] = gi < ng ? bits[((int64_t)rowc[r] * ng + gi) * 16 + n16] : 0ull;
-                }
-            const char* Bt = Bbuf + buf * BTILE;
+                for (int d = 0; d < 4; ++d)
+                    bf[d] = *reinterpret_cast<const v4i*>(Bt + d * (VCH * BROW) + ks * 64 + kh * 32);
+            };
+            v4i bf[2][4];
+            read_b(0, 0, bf[0]);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if (t * UT + ks * 64 + 63 <= v0) continue;  // entirely on or above the diagonal (uniform)
-                v4i bf[2][4];
+                load_masks(t * 4 + ks + 1, wb[(ks + 1) & 1]);  // next step (possibly of the next tile)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int kh = 0; kh < 2; ++kh) {
+                    const int hh = ks * 2 + kh;
+                    if (hh + 1 < 8) read_b((hh + 1) >> 1, (hh + 1) & 1, bf[(hh + 1) & 1]);  // next 32-column half
+                    if (t * UT + ks * 64 + kh * 32 + 31 <= v0) continue;  // entirely on or above the diagonal (uniform)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        bf[nt][p] = *reinterpret_cast<const v4i*>(Bt + (p * VCH + nt * 16 + n16) * BROW + ks * 64 + 16 * g);
+                    for (int p = 0; p < RW / 2; ++p) {
+                        const uint32_t b16 = (uint32_t)(wb[ks & 1][p] >> (32 * kh + 16 * kb)) & 0xffffu;
+                        v4i af;
 #pragma unroll
-                for (int r = 0; r < RW; ++r) {
-                    const uint32_t b16 = (uint32_t)(wbits[r][ks] >> (16 * g)) & 0xffffu;
-                    v4i af;
+                        for (int d = 0; d < 4; ++d) af[d] = (int)((((b16 >> (4 * d)) & 0xfu) * 0x00204081u) & 0x01010101u);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) af[d] = (int)((((b16 >> (4 * d)) & 0xfu) * 0x00204081u) & 0x01010101u);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int p = 0; p < 4; ++p)
-                            acc[r][nt][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[nt][p], acc[r][nt][p], 0, 0, 0);
+                        for (int d = 0; d < 4; ++d)
+                            acc[p][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[hh & 1][d], acc[p][d], 0, 0, 0);
+                    }
                 }
             }
             if (t + 1 < ntile) sstore(buf ^ 1);
             __syncthreads();
         }
-        // bucket the chunk's columns by their code: Mrow[a][b] += sum_p 256^p Y_p[a][v], b = Q[row][v]
+        { const long long tt = __builtin_amdgcn_s_memtime(); st_loop += tt - st_t0; st_t0 = tt; }
+        // bucket the chunk's columns by their code: Mrow[row][a][b] += sum_d 256^d Y_d[(row, a)][v], b = Q[row][v]
+        // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        {
+            const int v = v0 + i32;
 #pragma unroll
-        for (int r = 0; r < RW; ++r)
+            for (int p = 0; p < RW / 2; ++p) {
+                uint32_t bq[2];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int v = v0 + nt * 16 + n16;
-                const uint32_t b = v < n ? Q[(int64_t)rowc[r] * n + v] : 255u;
+                for (int h = 0; h < 2; ++h) bq[h] = v < n ? Q[(int64_t)rowc[2 * p + h] * n + v] : 255u;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long long val = (long long)acc[r][nt][0][i] + ((long long)acc[r][nt][1][i] << 8) +
-                                          ((long long)acc[r][nt][2][i] << 16) + ((long long)acc[r][nt][3][i] << 24);
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * kb;  // (row of the pair, code)
+                    const int h = i >> 4, a = i & 15;
+                    const long long val = (long long)acc[p][0][reg] + ((long long)acc[p][1][reg] << 8) +
+                                          ((long long)acc[p][2][reg] << 16) + ((long long)acc[p][3][reg] << 24);
+                    const uint32_t b = bq[h];
                     if (b < 16u && val != 0)
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&Mrow[wv][r][(4 * g + i) * 16 + b]),
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&Mrow[wv][2 * p + h][a * 16 + b]),
                                   (unsigned long long)val);
                 }
             }
+        }
+        { const long long tt = __builtin_amdgcn_s_memtime(); st_flush += tt - st_t0; st_t0 = tt; }
     }
+    if (stamps && blockIdx.x == 0 && tid == 0) { stamps[0] = st_pro; stamps[1] = st_loop; stamps[2] = st_flush; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -618,8 +642,18 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
     {
         ProfScope prof(KID_SHT_ACCUM, stream);
         const int nrg = (int)((m + TR - 1) / TR);
+        static const bool dbg = getenv("GANQ_ACCUM_DEBUG") != nullptr;  // developer timing experiment
+        long long* stamps = nullptr;
+        if (dbg) (void)hipMalloc(&stamps, 64);
         hipLaunchKernelGGL(onehot_accum_kernel, dim3((unsigned)(nrg * NP)), dim3(TW * 64), smem, stream, planes, bits, Q, (int)m,
-                           (int)n, (int)lo.nq, (int)lo.ng, mpart);
+                           (int)n, (int)lo.nq, (int)lo.ng, mpart, stamps);
+        if (stamps) {
+            long long h[3];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h, stamps, 24, hipMemcpyDeviceToHost);
+            (void)hipFree(stamps);
+            fprintf(stderr, "[onehot_accum stamps] wg0 wave0: prologue %lld, tile loop %lld, flush %lld cycles\n", h[0], h[1], h[2]);
+        }
     }
     GANQ_LAUNCH_CHECK();
     {
