@@ -45,6 +45,7 @@ def build_workload(args, dist, dev):
     import torch.nn as nn
 
     from ganq_amd import _lib
+    from ganq_amd import distributed as gdist
     from ganq_amd.looper.named_module import NamedModule
     from ganq_amd.quantization import GANQ, QuantizeConfig
 
@@ -87,7 +88,7 @@ def build_workload(args, dist, dev):
         if dist.world > 1:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            td.broadcast(x, src=0)  # RCCL over xGMI: calibration activations to every owner rank
+            gdist.broadcast_tensor(x, 0)  # RCCL over xGMI: calibration activations to every owner rank
             torch.cuda.synchronize()
             t_bcast += time.perf_counter() - t0
         t0 = time.perf_counter()
@@ -144,8 +145,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--layer-m", dest="m", type=int, default=4096)
+    ap.add_argument("--layer-n", dest="n", type=int, default=4096)
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--iters", type=int, default=10, help="GANQ iterations K (README PPL numbers use 10)")
     ap.add_argument("--nseq", type=int, default=128)
@@ -190,7 +191,9 @@ def main():
     prof = _lib.profile_report()
     _lib.profile_enable(False)
     if dist.world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if td.get_backend() != "gloo":
+            t = t.to(dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t)
 

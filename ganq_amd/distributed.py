@@ -38,7 +38,10 @@ class Dist:
 
 
 def init_from_env(backend: Optional[str] = None) -> Dist:
-    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as set by torch.distributed.run"""
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as set by torch.distributed.run.
+
+    One process per GPU, backend "nccl" (= RCCL).  For rehearsing the multi-rank code path on a box with fewer GPUs
+    than ranks, GANQ_DIST_SHARE_DEVICE=1 maps every rank to cuda:0 and uses gloo (RCCL refuses two ranks on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         if torch.cuda.is_available():
@@ -46,13 +49,26 @@ def init_from_env(backend: Optional[str] = None) -> Dist:
         return Dist(0, 1, torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu"))
     local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     use_cuda = torch.cuda.is_available()
+    share = os.environ.get("GANQ_DIST_SHARE_DEVICE", "") == "1"
     if use_cuda:
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(0 if share else local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if not td.is_initialized():
-        td.init_process_group(backend or ("nccl" if use_cuda else "gloo"))
+        td.init_process_group(backend or ("gloo" if (share or not use_cuda) else "nccl"))
     return Dist.current()
+
+
+def broadcast_tensor(t: torch.Tensor, src: int) -> torch.Tensor:
+    """in-place broadcast; under gloo (rehearsal / CPU tests) device tensors are staged through the host"""
+    if td.get_backend() == "gloo" and t.is_cuda:
+        host = t.detach().cpu()
+        td.broadcast(host, src=src)
+        if td.get_rank() != src:
+            t.copy_(host)
+    else:
+        td.broadcast(t, src=src)
+    return t
 
 
 def module_cost(m: int, n: int) -> float:
@@ -88,15 +104,24 @@ def broadcast_activations(x: Optional[torch.Tensor], shape, dtype, src: int, dis
     if dist.world == 1:
         return x
     buf = x if dist.rank == src else torch.empty(shape, dtype=dtype, device=dist.device)
-    td.broadcast(buf, src=src)
-    return buf
+    return broadcast_tensor(buf, src)
+
+
+def allreduce_sum(t: torch.Tensor) -> torch.Tensor:
+    if td.get_backend() == "gloo" and t.is_cuda:
+        host = t.cpu()
+        td.all_reduce(host, op=td.ReduceOp.SUM)
+        t.copy_(host)
+    else:
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t
 
 
 def allreduce_hessian(H: torch.Tensor, dist: Dist) -> torch.Tensor:
     """data-parallel calibration: every rank accumulated H over ITS share of the sequences with the global
     sample count as normaliser (H = (2/N) sum_b X_b^T X_b is a plain sum, gptq.py:122-131)"""
     if dist.world > 1:
-        td.all_reduce(H, op=td.ReduceOp.SUM)
+        allreduce_sum(H)
     return H
 
 
@@ -110,15 +135,17 @@ def share_module_result(processor, named_module, owner: int, dist: Dist):
     if dist.rank == owner:
         meta[0] = 1 if res is not None else 0
         meta[1] = res["bits"] if res is not None else 0
-    td.broadcast(meta, src=owner)
+    broadcast_tensor(meta, owner)
     if int(meta[0]) == 0:
         return  # module was skipped by the owner
     bits = int(meta[1])
     wq = lin.weight.data if dist.rank == owner else torch.empty_like(lin.weight.data)
     q = res["ganq_q"] if dist.rank == owner else torch.empty((m, n), dtype=torch.uint8, device=dev)
     lut = res["ganq_lut"] if dist.rank == owner else torch.empty((m, 2 ** bits), dtype=torch.float32, device=dev)
+    if dist.rank == owner:
+        wq, q, lut = wq.contiguous(), q.contiguous(), lut.contiguous()
     for t in (wq, q, lut):
-        td.broadcast(t.contiguous() if dist.rank == owner else t, src=owner)
+        broadcast_tensor(t, owner)
     if dist.rank != owner:
         lin.weight.data = wq
         named_module.state.update({"wq": wq, "ganq_q": q, "ganq_lut": lut})
@@ -172,7 +199,7 @@ def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: floa
         ds.append(d)
     dists = torch.cat(ds)
     if dist.world > 1:
-        td.all_reduce(dists, op=td.ReduceOp.SUM)  # best-of-K is global over rows (ganq.py:622-626)
+        allreduce_sum(dists)  # best-of-K is global over rows (ganq.py:622-626)
     best_k = int(torch.argmin(dists))  # first minimum == the reference's strict `<` scan
     T_loc = Ts[best_k]
     Q_loc = Qs[K - 1] if alias_q else Qs[best_k]
@@ -184,7 +211,7 @@ def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: floa
         if b > a:
             tt = T_loc if r == dist.rank else torch.empty((b - a, V), dtype=T0.dtype, device=W.device)
             qq = Q_loc if r == dist.rank else torch.empty((b - a, n), dtype=torch.uint8, device=W.device)
-            td.broadcast(tt, src=r)
-            td.broadcast(qq, src=r)
+            broadcast_tensor(tt, r)
+            broadcast_tensor(qq, r)
             T_full[a:b], Q_full[a:b] = tt, qq
     return T_full, Q_full, dists, best_k

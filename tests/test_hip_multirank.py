@@ -1,0 +1,84 @@
+"""GPU rehearsal of the N>1 paths with two ranks sharing the one GPU of the test box (gloo, GANQ_DIST_SHARE_DEVICE=1;
+RCCL refuses two ranks on one device): row-sharded loop and module dispatch in the looper, both against the
+single-rank HIP result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), GANQ_DIST_SHARE_DEVICE="1")
+    import torch.distributed as td
+    import torch.nn as nn
+
+    from ganq_amd import _lib
+    from ganq_amd import distributed as gdist
+    from ganq_amd.looper.gptq_processor import GPTQProcessor
+    from ganq_amd.looper.module_looper import ModuleLooper
+    from ganq_amd.quantization import QuantizeConfig
+    from test_hip_stages import synth
+
+    dist = gdist.init_from_env()
+    try:
+        W, H, L, T0 = (torch.from_numpy(a).cuda() for a in synth(80, 256, 16, 77, corr=0.2))
+        T, Q, dists, best_k = gdist.run_layer_row_sharded(W, H, L, T0, 3, alias_q=True, dist=dist)
+        T1, Q1, d1, b1 = _lib.run_layer(W, H, L, T0, 3, alias_q=True)
+        ok_rows = bool(torch.equal(Q, Q1)) and best_k == int(b1) and torch.allclose(dists, d1, rtol=1e-9)
+        ok_rows = ok_rows and float((T - T1).norm() / T1.norm()) < 1e-6
+
+        torch.manual_seed(0)  # same model on both ranks
+        layer = nn.ModuleDict({"q_proj": nn.Linear(64, 64, bias=False), "k_proj": nn.Linear(64, 32, bias=False),
+                               "v_proj": nn.Linear(64, 32, bias=False)}).half().cuda()
+
+        class Blk(nn.Module):
+            def __init__(self, d):
+                super().__init__()
+                self.q_proj, self.k_proj, self.v_proj = d["q_proj"], d["k_proj"], d["v_proj"]
+
+            def forward(self, x):
+                return x + self.q_proj(x) + torch.cat([self.k_proj(x), self.v_proj(x)], -1)
+
+        blk = Blk(layer)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        xs = [torch.randn(2, 40, 64, device="cuda", generator=g).half() for _ in range(3)]
+        proc = GPTQProcessor(QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2))
+        with torch.no_grad():
+            ModuleLooper(proc, [blk], [["q_proj", "k_proj", "v_proj"]], layers_prefix="layers").loop(xs)
+        owners = gdist.assign({"q_proj": (64, 64), "k_proj": (32, 64), "v_proj": (32, 64)}, world)
+        mine = sorted(n for n, r in owners.items() if r == rank)
+        state = {k: v.float().cpu().numpy() for k, v in blk.state_dict().items()}
+        out_q.put((rank, ok_rows, mine, sorted(proc.results()), state))
+    except Exception as e:  # report instead of letting the parent wait for its queue timeout
+        out_q.put((rank, False, [f"ERROR {type(e).__name__}: {e}"], [], {}))
+        raise
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu():
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = 29800 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((out_q.get(timeout=150) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ok0, mine0, names0, st0), (r1, ok1, mine1, names1, st1) = res
+    assert ok0 and ok1, f"row-sharded loop differs from the single-rank result / worker error: {mine0} {mine1}"
+    assert mine0 and mine1 and not set(mine0) & set(mine1)          # the group's modules were split over the ranks
+    assert names0 == names1 and len(names0) == 3                      # both ranks hold every result afterwards
+    for k in st0:
+        assert np.array_equal(st0[k], st1[k]), k                      # and identical quantized weights
