@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
+INT8_MFMA_PEAK_TOPS = 5000.0    # MI355X_MICROARCH.md: i8 MFMA = 2x the bf16 rate per clock, bf16 dense ~2.5 PF
 
 
 def log(*a):
@@ -205,21 +206,34 @@ def main():
         dom_name, (dom_ms, dom_cnt) = dom
         avg_s = dom_ms / dom_cnt / 1e3
         if dom_name == "solve_s_kernel":
-            flops = float(m) * n * (n - 1)  # residual chain: n(n-1)/2 fused multiply-adds per row
-            roof = {"kernel": dom_name, "bound": "mfma", "achieved": round(flops / avg_s / 1e12, 3),
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            work = float(m) * n * (n - 1)  # residual chain: n(n-1)/2 fused multiply-adds per row, fp32 matrix cores
+            roof = {"kernel": dom_name, "bound": "mfma", "achieved": round(work / avg_s / 1e12, 3),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "peak_dtype": "f32"}
+        elif dom_name == "onehot_accum_kernel":
+            # bucket sum of H per row on the int8 matrix cores: one-hot [16 codes] x 4 digit planes, pairs u > v only
+            work = 2.0 * 16 * 4 * m * n * (n - 1) / 2
+            roof = {"kernel": dom_name, "bound": "mfma", "achieved": round(work / avg_s / 1e12, 3),
+                    "peak": INT8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "peak_dtype": "i8 (dense, 2x bf16)"}
         elif dom_name == "gemm_f32_kernel":
-            flops = 2.0 * m * n * n
-            roof = {"kernel": dom_name, "bound": "mfma", "achieved": round(flops / avg_s / 1e12, 3),
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            work = 2.0 * m * n * n
+            roof = {"kernel": dom_name, "bound": "mfma", "achieved": round(work / avg_s / 1e12, 3),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "peak_dtype": "f32"}
         else:
-            # T-update accumulation: algorithmic bytes = H once (4 n^2) + Q (m n) + per-chunk partial A out
-            nbytes = 4.0 * n * n + 1.0 * m * n + 4.0 * m * V * V * ((n + 127) // 128)
+            nbytes = 4.0 * n * n + 1.0 * m * n
             roof = {"kernel": dom_name, "bound": "hbm", "achieved": round(nbytes / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 5)
         roof["avg_launch_ms"] = round(dom_ms / dom_cnt, 4)
-        roof["traffic"] = None  # HBM bytes from PMC counters live in profiles/ (separate rocprofv3 --pmc pass)
+        # HBM bytes per launch from the PMC counters of a separate rocprofv3 --pmc pass over the same kernels
+        # (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        roof["traffic"] = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            for k, v in pmc.items():
+                if k.split("<")[0] == dom_name and (m, n) == (4096, 4096):
+                    roof["traffic"] = int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
+        except (OSError, ValueError, KeyError):
+            pass
         # whole-path HBM view: algorithmic bytes of the loop per layer / loop time
         b_loop = K * (15.0 * m * n + 10.0 * n * n + 8.0 * m * V)
         path_gbs = b_loop / (elapsed / args.steps) / 1e9
