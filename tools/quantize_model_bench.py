@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Full-model GANQ quantization timing on a random-initialised architecture (BASELINE.json configs[1]/[2] shape:
+opt-125m / Llama-3.2-1B, 4-bit, 128 x 2048 synthetic calibration tokens).  No network: weights are random, so this
+measures time and self-consistency, not perplexity against the published numbers.
+
+    python tools/quantize_model_bench.py --arch opt-125m --nsamples 128 --seqlen 2048 --iters 10
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ARCHS = {
+    "opt-125m": ("opt", dict(vocab_size=50272, hidden_size=768, ffn_dim=3072, num_hidden_layers=12, num_attention_heads=12,
+                             max_position_embeddings=2048, word_embed_proj_dim=768)),
+    "opt-350m-like": ("opt", dict(vocab_size=50272, hidden_size=1024, ffn_dim=4096, num_hidden_layers=24,
+                                  num_attention_heads=16, max_position_embeddings=2048, word_embed_proj_dim=1024)),
+    "llama-3.2-1b": ("llama", dict(vocab_size=128256, hidden_size=2048, intermediate_size=8192, num_hidden_layers=16,
+                                   num_attention_heads=32, num_key_value_heads=8, max_position_embeddings=131072,
+                                   rope_theta=500000.0, tie_word_embeddings=True)),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="opt-125m", choices=sorted(ARCHS))
+    ap.add_argument("--nsamples", type=int, default=128)
+    ap.add_argument("--seqlen", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--layers", type=int, default=0, help="truncate the model to this many layers (0 = all)")
+    a = ap.parse_args()
+    import transformers
+
+    from ganq_amd.models import gptq_style_ppl, quantize_model
+    from ganq_amd.quantization import QuantizeConfig
+
+    kind, kw = ARCHS[a.arch]
+    if a.layers:
+        kw = dict(kw, num_hidden_layers=a.layers)
+    torch.manual_seed(0)
+    cfg = (transformers.OPTConfig if kind == "opt" else transformers.LlamaConfig)(**kw)
+    model = (transformers.OPTForCausalLM if kind == "opt" else transformers.LlamaForCausalLM)(cfg).half().cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    calib = [torch.randint(0, cfg.vocab_size, (a.batch, a.seqlen), generator=g) for _ in range(a.nsamples // a.batch)]
+    test_ids = torch.randint(0, cfg.vocab_size, (1, a.seqlen * 4), generator=g)
+    ppl_fp = gptq_style_ppl(model, test_ids, a.seqlen)
+    qcfg = QuantizeConfig(bits=a.bits, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=a.iters,
+                          damp_percent=0.01, desc_act=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    proc = quantize_model(model, calib, qcfg)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ppl_q = gptq_style_ppl(model, test_ids, a.seqlen)
+    quant_s = sum(float(r["time"]) for r in proc.log)
+    cols = sum(m.in_features for m in model.modules() if type(m).__name__ == "GanqHipQuantLinear")
+    print(json.dumps({"arch": a.arch, "layers": cfg.num_hidden_layers, "modules": len(proc.log), "bits": a.bits,
+                      "ganq_iterations": a.iters, "calibration": f"{a.nsamples}x{a.seqlen} synthetic tokens",
+                      "total_s": round(dt, 3), "sum_module_quantize_s": round(quant_s, 3),
+                      "weight_columns": cols, "columns_per_s_whole_run": round(cols / dt, 1),
+                      "ppl_random_init_fp16": round(ppl_fp, 2), "ppl_random_init_ganq": round(ppl_q, 2)}))
+
+
+if __name__ == "__main__":
+    main()
