@@ -51,6 +51,7 @@ SIGNATURES = {
                                       ctypes.c_uint32, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
                                       _c_vp]),
     "ganq_lut_linear_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, ctypes.c_int]),
+    "ganq_lut_linear_workspace_init": (ctypes.c_int, [_c_vp, _c_sz, _c_vp]),
     "ganq_lut_linear_fwd": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64,
                                            ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_lut_dequant": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
@@ -327,8 +328,21 @@ def lut_dequant(qweight, lut, n: int, bits: int):
     return Wq
 
 
+_LUT_WS = {}  # (device index, stream) -> zero-initialised workspace, kept across calls (the kernel leaves it clean)
+
+
+def _lut_workspace(nbytes: int, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    ws = _LUT_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _check(lib().ganq_lut_linear_workspace_init(ws.data_ptr(), ws.numel(), _stream()), "ganq_lut_linear_workspace_init")
+        _LUT_WS[key] = ws
+    return ws
+
+
 def lut_linear(x, qweight, lut, bias, bits: int):
-    """x [M,n] (M <= 16) fp16/bf16, qweight int32 [n*bits/32, m], lut [m,V], bias [m] or None -> y [M,m]."""
+    """x [M,n] (M <= 64) fp16/bf16, qweight int32 [n*bits/32, m], lut [m,V], bias [m] or None -> y [M,m]."""
     code = _act_dtype(x, "x")
     if lut.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype):
         raise GanqHipError("x, lut and bias must share one dtype")
@@ -336,7 +350,7 @@ def lut_linear(x, qweight, lut, bias, bits: int):
     M, n = x.shape
     m = lut.shape[0]
     y = torch.empty((M, m), dtype=x.dtype, device=x.device)
-    ws = _workspace(lib().ganq_lut_linear_workspace_bytes(M, m, n, bits), x.device)
+    ws = _lut_workspace(lib().ganq_lut_linear_workspace_bytes(M, m, n, bits), x.device)
     _check(lib().ganq_lut_linear_fwd(x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), code, M, m, n, bits,
                                      y.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ganq_lut_linear_fwd")
     return y

@@ -6,8 +6,8 @@
 // 32-bit words laid out qweight[n*bits/32][m] -- exactly the GPTQ int32 packing (qlinear/__init__.py:508-538,
 // including its 3-bit 32-in-3-words scheme, which is the same bit stream); lut [m][V] in the activation dtype.
 //
-// ganq_lut_linear_fwd (M <= 16 rows, decode): one lane per output feature, the wave streams its features'
-//   words (coalesced 256 B per word row), looks the codebook up in an LDS copy of lut and accumulates in fp32;
+// ganq_lut_linear_fwd (M <= 64 rows, decode / small batches): weights are decoded straight into the B operand of
+//   v_mfma_f32_16x16x32_{f16,bf16} (codebook lookups in LDS), activations are the A operand, fp32 accumulation;
 //   the in_features range is split over workgroups and waves (deterministic two-stage reduction).
 // ganq_lut_dequant: materialises W_q [m,n] in the activation dtype for large-M products (prefill), which the
 //   host side hands to a library GEMM.
@@ -35,79 +35,230 @@ __device__ __forceinline__ uint32_t extract(const uint32_t (&w)[BITS], int j) {
     return v & ((1u << BITS) - 1u);
 }
 
-constexpr int LW = 4;  // waves per workgroup
+constexpr int LW = 4;          // waves per workgroup
+constexpr int LUT_MAX_M = 64;  // rows of x one call takes (4 row tiles of 16)
+constexpr int LUT_FB = 32 * LW;  // output features per workgroup
 
-template <int BITS, int MT>
-__global__ __launch_bounds__(LW * 64) void lut_gemv_kernel(const void* __restrict__ x, const uint32_t* __restrict__ qw,
-                                                          const void* __restrict__ lut, int dtype, int M, int m, int n,
-                                                          int groups_per_wave, float* __restrict__ partial) {
-    constexpr int V = 1 << BITS;
-    __shared__ float tbl[64][V + 1];
-    __shared__ float xs[LW][32][MT];
-    __shared__ float red[LW][MT][64];
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int o0 = blockIdx.x * 64;
-    const int ks = blockIdx.y;
-    const int o = o0 + lane;
-    const int oc = min(o, m - 1);
-    for (int i = tid; i < 64 * V; i += LW * 64) {
-        const int ol = i / V, e = i % V;
-        tbl[ol][e] = load_act(lut, (int64_t)min(o0 + ol, m - 1) * V + e, dtype);
-    }
-    __syncthreads();
-
-    const int ngroups = n >> 5;
-    const int g_begin = (ks * LW + wv) * groups_per_wave;
-    const int g_end = min(ngroups, g_begin + groups_per_wave);
-    for (int r0 = 0; r0 < M; r0 += MT) {
-        float acc[MT];
-#pragma unroll
-        for (int r = 0; r < MT; ++r) acc[r] = 0.f;
-        for (int g = g_begin; g < g_end; ++g) {
-            // activations of this group: 32 x MT values, wave-private LDS slab
-            if (lane < 32) {
-#pragma unroll
-                for (int r = 0; r < MT; ++r)
-                    xs[wv][lane][r] = (r0 + r < M) ? load_act(x, (int64_t)(r0 + r) * n + 32 * g + lane, dtype) : 0.f;
-            }
-            uint32_t w[BITS];
-#pragma unroll
-            for (int b = 0; b < BITS; ++b) w[b] = qw[(int64_t)(g * BITS + b) * m + oc];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const float wq = tbl[lane][extract<BITS>(w, j)];
-#pragma unroll
-                for (int r = 0; r < MT; ++r) acc[r] = fmaf(xs[wv][j][r], wq, acc[r]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-#pragma unroll
-        for (int r = 0; r < MT; ++r) red[wv][r][lane] = acc[r];
-        __syncthreads();
-        if (wv == 0) {
-#pragma unroll
-            for (int r = 0; r < MT; ++r) {
-                float s = red[0][r][lane];
-#pragma unroll
-                for (int w2 = 1; w2 < LW; ++w2) s += red[w2][r][lane];
-                if (o < m && r0 + r < M) partial[((int64_t)ks * M + r0 + r) * m + o] = s;
-            }
-        }
-        __syncthreads();
-    }
+// two codebook entries (dword slots holding a 16-bit value) -> one packed register.  (The d16 / d16_hi LDS loads
+// cannot be used for this: with SRAM-ECC on, as on gfx950, they overwrite the whole register.)
+__device__ __forceinline__ uint32_t lds_pair(uint32_t addr_lo, uint32_t addr_hi) {
+    typedef const uint32_t __attribute__((address_space(3))) * lds_u32;
+    return *reinterpret_cast<lds_u32>(addr_lo) | (*reinterpret_cast<lds_u32>(addr_hi) << 16);
 }
 
-__global__ __launch_bounds__(256) void lut_finish_kernel(const float* __restrict__ partial, const void* __restrict__ bias,
-                                                         int dtype, int KS, int M, int m, void* __restrict__ y) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)M * m) return;
-    const int o = (int)(i % m);
-    float s = 0.f;
-    for (int k = 0; k < KS; ++k) s += partial[(int64_t)k * M * m + i];
-    if (bias) s += load_act(bias, o, dtype);
-    static_cast<uint16_t*>(y)[i] = store_act(s, dtype);
+// decode kernel on the 16x16x32 matrix-core tile: D[row][feature] += x[row][k] * Wq[feature][k].
+//   B operand (weights): lane l holds feature l%16 and the 8 consecutive in_features 8*(l/16).. of a 32-column
+//   group, i.e. exactly 8*BITS consecutive bits of that feature's stream: one word load (two for 3-bit), 8 codebook
+//   lookups, 4 packs.  A operand (activations): lane l holds row l%16, the same 8
+//   in_features: one 16 B load.
+//   A workgroup owns 128 features (each wave two B tiles sharing A: the workgroup reads 512 B of every word row)
+//   and a range of 32-column groups (blockIdx.y); the waves share the activation loads through L1.
+//   tbl[wave][t][e][lane]: codebook entry e of lane's feature in tile t, one dword slot per lane and entry, so the
+//   per-lane dynamic lookup is bank-conflict free.
+//   Split-K: each workgroup stores its partial tile, takes a ticket on the feature block's counter, and the last
+//   one to arrive sums the partials in ks order (deterministic), adds the bias and writes y; it leaves the counter 0.
+template <int BITS, int RT, bool BF16>
+__global__ __launch_bounds__(LW * 64) void lut_mfma_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                          const uint16_t* __restrict__ lut, const uint16_t* __restrict__ bias,
+                                                          int M, int m, int n, int kb_per_wg, int KS,
+                                                          float* __restrict__ partial, int* __restrict__ counters,
+                                                          uint16_t* __restrict__ y) {
+    constexpr int V = 1 << BITS;
+    constexpr int KC = 4;  // groups in flight per wave (loads issued one chunk ahead)
+    constexpr bool STRADDLE = (8 * BITS) % 16 != 0;  // 3-bit: a lane's 24 bits can span two words
+    __shared__ __attribute__((aligned(4096))) uint32_t tbl[LW][2][V][64];  // 4 KB alignment: see the v_perm addressing
+    __shared__ int s_ticket;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, q = lane >> 4;
+    const int o0 = blockIdx.x * LUT_FB + 32 * wv, ks = blockIdx.y;
+    const int nkb = n >> 5;
+    const int kb_begin = ks * kb_per_wg;
+    const int kb_end = min(nkb, kb_begin + kb_per_wg);  // kb_begin < nkb by construction of the grid
+    const int off = 8 * BITS * q, wi = off >> 5, sh = off & 31;
+    const int wi2 = STRADDLE ? min(wi + 1, BITS - 1) : wi;
+    const int oc0 = min(o0 + col, m - 1), oc1 = min(o0 + 16 + col, m - 1);
+
+    uint32_t wl[2][KC][2], wh[2][KC][2];
+    u32x4 xa[2][KC][RT];
+    auto issue = [&](int buf, int kb0) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int kb = kb0 + c;
+            const bool ok = kb < kb_end;
+            const int kbc = ok ? kb : kb_begin;
+            const int64_t row = (int64_t)(kbc * BITS + wi) * m, row2 = (int64_t)(kbc * BITS + wi2) * m;
+            wl[buf][c][0] = qw[row + oc0];
+            wl[buf][c][1] = qw[row + oc1];
+            if (STRADDLE) {
+                wh[buf][c][0] = qw[row2 + oc0];
+                wh[buf][c][1] = qw[row2 + oc1];
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int xr = 16 * r + col;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok && xr < M) v = *reinterpret_cast<const u32x4*>(x + (int64_t)xr * n + 32 * kbc + 8 * q);
+                xa[buf][c][r] = v;
+            }
+        }
+    };
+    f32x4 acc[2][RT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, kb_begin);  // weights and activations are in flight while the table is built
+    {   // every lane fetches the V entries of its own feature (rows of lut are 2V bytes, 4-byte aligned)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t* lp = reinterpret_cast<const uint32_t*>(lut + (int64_t)(t ? oc1 : oc0) * V);
+            uint32_t h[V / 2];
+#pragma unroll
+            for (int e = 0; e < V / 2; ++e) h[e] = lp[e];
+#pragma unroll
+            for (int e = 0; e < V / 2; ++e) {
+                tbl[wv][t][2 * e][lane] = h[e] & 0xffffu;
+                tbl[wv][t][2 * e + 1][lane] = h[e] >> 16;
+            }
+        }
+    }
+    __syncthreads();  // tbl ready (each wave reads only its own part; the barrier orders the LDS writes)
+
+    // LDS byte address of entry e: tb0 + 256*e + 4*lane (+ 256*V for tile 1)
+    const uint32_t tb0 = (uint32_t)(uintptr_t)(&tbl[0][0][0][0]) + (uint32_t)wv * (2u * V * 256u);
+    const uint32_t lane4 = 4u * lane;
+    auto consume = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            u32x4 b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint32_t bits = wl[buf][c][t] >> sh;
+                if (STRADDLE) bits = (uint32_t)((((uint64_t)wh[buf][c][t] << 32) | wl[buf][c][t]) >> sh);
+                const uint32_t tb = tb0 + (uint32_t)t * (V * 256u);
+                if (BITS == 4) {
+                    // byte k of lo/hi = entry index of element 2k / 2k+1, OR-ed with byte 1 of the (4 KB aligned) tile base:
+                    // one v_perm per address ({byte1, byte0} = {index | base, 4*lane})
+                    const uint32_t hib = ((tb >> 8) & 0xffu) * 0x01010101u;
+                    const uint32_t lo = (bits & 0x0f0f0f0fu) | hib, hi = ((bits >> 4) & 0x0f0f0f0fu) | hib;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        b[t][p] = lds_pair(__builtin_amdgcn_perm(lo, lane4, 0x0c0c0000u | ((4u + p) << 8)),
+                                               __builtin_amdgcn_perm(hi, lane4, 0x0c0c0000u | ((4u + p) << 8)));
+                } else {
+                    const uint32_t base = tb + lane4;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        b[t][p] = lds_pair((((bits >> (BITS * (2 * p))) & (V - 1)) << 8) + base,
+                                               (((bits >> (BITS * (2 * p + 1))) & (V - 1)) << 8) + base);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (BF16)
+                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa[buf][c][r]),
+                                                                            __builtin_bit_cast(bf16x8, b[t]), acc[t][r], 0, 0, 0);
+                    else
+                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xa[buf][c][r]),
+                                                                           __builtin_bit_cast(f16x8, b[t]), acc[t][r], 0, 0, 0);
+                }
+        }
+    };
+    // groups past kb_end carry zero activations, so a ragged last chunk needs no special case
+    for (int kb0 = kb_begin; kb0 < kb_end; kb0 += 2 * KC) {
+        if (kb0 + KC < kb_end) issue(1, kb0 + KC);
+        consume(0);
+        if (kb0 + KC < kb_end) {
+            if (kb0 + 2 * KC < kb_end) issue(0, kb0 + 2 * KC);
+            consume(1);
+        }
+    }
+
+    auto finish = [&](float v, int row, int o) {
+        if (bias) v += BF16 ? __builtin_bit_cast(float, (uint32_t)bias[o] << 16) : (float)__builtin_bit_cast(_Float16, bias[o]);
+        y[(int64_t)row * m + o] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v) : __builtin_bit_cast(uint16_t, (_Float16)v);
+    };
+    if (KS == 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 16 * r + 4 * q + i, o = o0 + 16 * t + col;
+                    if (row < M && o < m) finish(acc[t][r][i], row, o);
+                }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * r + 4 * q + i, o = o0 + 16 * t + col;
+                if (row < M && o < m)
+                    __hip_atomic_store(&partial[((int64_t)ks * M + row) * m + o], acc[t][r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    // The partial tiles are written and read with device-scope (L2-bypassing, write-through) accesses, so no cache
+    // write-back / invalidate is needed around the ticket (a full __threadfence() costs ~60 us here: it walks L2):
+    // once vmcnt reaches 0 the stores are visible to every XCD, and the ticket is taken after that.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != KS - 1) return;
+    // all of this lane's outputs at once, KBT splits per batch: 64 independent loads in flight, sums in ks order
+    constexpr int KBT = 8 / RT;
+    float s[RT][4][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[r][i][0] = s[r][i][1] = 0.f;
+    for (int k0 = 0; k0 < KS; k0 += KBT) {
+        float v[KBT][RT][4][2];
+#pragma unroll
+        for (int u = 0; u < KBT; ++u)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = 16 * r + 4 * q + i, o = o0 + 16 * t + col;
+                        v[u][r][i][t] = (k0 + u < KS && row < M && o < m)
+                                            ? __hip_atomic_load(&partial[((int64_t)(k0 + u) * M + row) * m + o], __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT)
+                                            : 0.f;
+                    }
+#pragma unroll
+        for (int u = 0; u < KBT; ++u)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) s[r][i][t] += v[u][r][i][t];
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = 16 * r + 4 * q + i, o = o0 + 16 * t + col;
+                if (row < M && o < m) finish(s[r][i][t], row, o);
+            }
+    if (tid == 0) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next call
 }
 
 template <int BITS>
@@ -157,14 +308,29 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict_
     Q[i] = (uint8_t)(v & ((1u << bits) - 1u));
 }
 
-static void lut_split(int64_t m, int64_t n, int* KS, int* groups_per_wave) {
-    const int ngroups = (int)(n >> 5);
-    const int ob = (int)((m + 63) / 64);
-    int ks = std::max(1, std::min((ngroups + LW - 1) / LW, (1024 + ob - 1) / ob));
-    int gpw = (ngroups + ks * LW - 1) / (ks * LW);
-    ks = (ngroups + gpw * LW - 1) / (gpw * LW);
-    *KS = ks;
-    *groups_per_wave = gpw;
+struct LutPlan {
+    int ob, KS, kb_per_wg;
+    size_t counter_bytes, bytes;
+};
+static LutPlan lut_plan(int64_t M, int64_t m, int64_t n, int bits) {
+    // split in_features over blockIdx.y until the launch has enough workgroups for 256 CUs; fewer splits for taller x
+    // (the partial tiles are KS*M*m floats and the last workgroup of a feature block sums KS of them)
+    LutPlan p;
+    const int nkb = (int)(n >> 5);
+    p.ob = (int)((m + LUT_FB - 1) / LUT_FB);
+    static const int target_env = getenv("GANQ_LUT_WGS") ? atoi(getenv("GANQ_LUT_WGS")) : 0;
+    // measured on MI355X (tools/lut_trace.sh): ~512 workgroups, and at most 8 / 4 / 2 splits for M <= 16 / 32 / 64 --
+    // the exchange of partial tiles goes through memory (device-scope accesses) and its cost grows with KS * M
+    static const int cap_env = getenv("GANQ_LUT_KS") ? atoi(getenv("GANQ_LUT_KS")) : 0;
+    const int target = target_env > 0 ? target_env : 512;
+    const int cap = cap_env > 0 ? cap_env : (M <= 16 ? 8 : (M <= 32 ? 4 : 2));
+    int ks = std::max(1, std::min(std::min(nkb / 2, cap), (target + p.ob - 1) / p.ob));
+    (void)bits;
+    p.kb_per_wg = (nkb + ks - 1) / ks;
+    p.KS = (nkb + p.kb_per_wg - 1) / p.kb_per_wg;
+    p.counter_bytes = align_up((size_t)p.ob * sizeof(int), 256);
+    p.bytes = p.counter_bytes + (p.KS > 1 ? align_up((size_t)p.KS * (size_t)M * (size_t)m * sizeof(float), 256) : 0);
+    return p;
 }
 
 }  // namespace ganq
@@ -172,27 +338,41 @@ static void lut_split(int64_t m, int64_t n, int* KS, int* groups_per_wave) {
 using namespace ganq;
 
 extern "C" size_t ganq_lut_linear_workspace_bytes(int64_t M, int64_t m, int64_t n, int bits) {
-    (void)bits;
-    if (M <= 0 || m <= 0 || n <= 0) return 0;
-    int KS, gpw;
-    lut_split(m, n, &KS, &gpw);
-    return align_up((size_t)KS * (size_t)M * (size_t)m * sizeof(float), 256);
+    if (M <= 0 || m <= 0 || n < 32) return 0;
+    return lut_plan(M, m, n, bits).bytes;
+}
+
+extern "C" int ganq_lut_linear_workspace_init(void* workspace, size_t workspace_bytes, void* stream_) {
+    if (workspace_bytes == 0) return 0;
+    if (!workspace) return fail(-3, "ganq_lut_linear_workspace_init: null workspace");
+    GANQ_HIP_CHECK(hipMemsetAsync(workspace, 0, workspace_bytes, static_cast<hipStream_t>(stream_)));
+    return 0;
+}
+
+template <int BITS, int RT>
+static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, const void* bias, int dtype, int M, int m, int n,
+                         const LutPlan& p, float* partial, int* counters, void* y, hipStream_t stream) {
+    const dim3 grid((unsigned)p.ob, (unsigned)p.KS);
+    const uint16_t* xp = static_cast<const uint16_t*>(x);
+    const uint16_t* lp = static_cast<const uint16_t*>(lut);
+    const uint16_t* bp = static_cast<const uint16_t*>(bias);
+    uint16_t* yp = static_cast<uint16_t*>(y);
+    if (dtype == 1)
+        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, M, m, n,
+                           p.kb_per_wg, p.KS, partial, counters, yp);
+    else
+        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, M, m, n,
+                           p.kb_per_wg, p.KS, partial, counters, yp);
+    GANQ_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int BITS>
-static int launch_gemv(const void* x, const uint32_t* qw, const void* lut, int dtype, int M, int m, int n, int KS,
-                       int gpw, float* partial, hipStream_t stream) {
-    const dim3 grid((unsigned)((m + 63) / 64), (unsigned)KS);
-    if (M == 1)
-        hipLaunchKernelGGL((lut_gemv_kernel<BITS, 1>), grid, dim3(LW * 64), 0, stream, x, qw, lut, dtype, M, m, n, gpw, partial);
-    else if (M == 2)
-        hipLaunchKernelGGL((lut_gemv_kernel<BITS, 2>), grid, dim3(LW * 64), 0, stream, x, qw, lut, dtype, M, m, n, gpw, partial);
-    else if (M <= 4)
-        hipLaunchKernelGGL((lut_gemv_kernel<BITS, 4>), grid, dim3(LW * 64), 0, stream, x, qw, lut, dtype, M, m, n, gpw, partial);
-    else
-        hipLaunchKernelGGL((lut_gemv_kernel<BITS, 8>), grid, dim3(LW * 64), 0, stream, x, qw, lut, dtype, M, m, n, gpw, partial);
-    GANQ_LAUNCH_CHECK();
-    return 0;
+static int launch_lut(const void* x, const uint32_t* qw, const void* lut, const void* bias, int dtype, int M, int m, int n,
+                      const LutPlan& p, float* partial, int* counters, void* y, hipStream_t stream) {
+    if (M <= 16) return launch_lut_rt<BITS, 1>(x, qw, lut, bias, dtype, M, m, n, p, partial, counters, y, stream);
+    if (M <= 32) return launch_lut_rt<BITS, 2>(x, qw, lut, bias, dtype, M, m, n, p, partial, counters, y, stream);
+    return launch_lut_rt<BITS, 4>(x, qw, lut, bias, dtype, M, m, n, p, partial, counters, y, stream);
 }
 
 static int check_lut_args(const char* who, int dtype, int64_t m, int64_t n, int bits) {
@@ -210,27 +390,23 @@ extern "C" int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const 
     if (M == 0 || m == 0) return 0;
     int rc = check_lut_args("ganq_lut_linear_fwd", dtype, m, n, bits);
     if (rc) return rc;
-    if (M > 16) return fail(-2, "ganq_lut_linear_fwd: M=%lld > 16; use ganq_lut_dequant + a GEMM for large batches", (long long)M);
+    if (M > LUT_MAX_M)
+        return fail(-2, "ganq_lut_linear_fwd: M=%lld > %d; use ganq_lut_dequant + a GEMM for large batches", (long long)M, LUT_MAX_M);
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(-2, "ganq_lut_linear_fwd: x must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(lut) & 3) != 0) return fail(-2, "ganq_lut_linear_fwd: lut must be 4-byte aligned");
     if (!x || !qweight || !lut || !y) return fail(-3, "ganq_lut_linear_fwd: null pointer");
-    const size_t need = ganq_lut_linear_workspace_bytes(M, m, n, bits);
-    if (!workspace || workspace_bytes < need)
-        return fail(-4, "ganq_lut_linear_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
+    const LutPlan p = lut_plan(M, m, n, bits);
+    if (!workspace || workspace_bytes < p.bytes)
+        return fail(-4, "ganq_lut_linear_fwd: workspace %zu B < required %zu B", workspace_bytes, p.bytes);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    int KS, gpw;
-    lut_split(m, n, &KS, &gpw);
-    float* partial = static_cast<float*>(workspace);
+    int* counters = static_cast<int*>(workspace);
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.counter_bytes);
     const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
-    {
-        ProfScope prof(KID_LUT_GEMV, stream);
-        if (bits == 2) rc = launch_gemv<2>(x, qw, lut, dtype, (int)M, (int)m, (int)n, KS, gpw, partial, stream);
-        else if (bits == 3) rc = launch_gemv<3>(x, qw, lut, dtype, (int)M, (int)m, (int)n, KS, gpw, partial, stream);
-        else rc = launch_gemv<4>(x, qw, lut, dtype, (int)M, (int)m, (int)n, KS, gpw, partial, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(lut_finish_kernel, dim3((unsigned)((M * m + 255) / 256)), dim3(256), 0, stream, partial, bias, dtype,
-                           KS, (int)M, (int)m, y);
-    }
-    GANQ_LAUNCH_CHECK();
-    return 0;
+    ProfScope prof(KID_LUT_GEMV, stream);
+    if (bits == 2) rc = launch_lut<2>(x, qw, lut, bias, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    else if (bits == 3) rc = launch_lut<3>(x, qw, lut, bias, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    else rc = launch_lut<4>(x, qw, lut, bias, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    return rc;
 }
 
 extern "C" int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dtype, int64_t m, int64_t n, int bits,

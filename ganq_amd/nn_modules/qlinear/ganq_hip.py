@@ -20,7 +20,7 @@ from ... import _lib
 from . import BaseQuantLinear
 
 BACKEND_GANQ_HIP = "ganq_hip"
-GEMV_MAX_ROWS = 16
+GEMV_MAX_ROWS = 64
 
 
 class GanqHipQuantLinear(BaseQuantLinear):

@@ -105,8 +105,13 @@ int ganq_run_layer(const float* W, const float* H, const float* L, int64_t ldl, 
  * y[M,m] = x[M,n] @ dequant(qweight, lut)^T + bias.   dtype: 0 = fp16, 1 = bf16 (x, lut, bias, y).
  * qweight: indices packed `bits` per index along the in_features dimension in the GPTQ int32
  * layout qweight[n*bits/32, m] (qlinear/__init__.py:508-517); lut [m,V]; bias [m] or NULL.     */
-/* decode path, M <= 16 rows; workspace: ganq_lut_linear_workspace_bytes() */
+/* decode / small-batch path, M <= 64 rows, x 16-byte aligned.  One kernel: split-K partial tiles plus one ticket
+ * counter per block of 128 features live in the workspace; the last workgroup of a block reduces and writes y.
+ * The workspace must be zero-filled ONCE after allocation (ganq_lut_linear_workspace_init); every call leaves the
+ * counters zero again, so it can be reused by later calls of any shape that fits.  One workspace serves one stream
+ * at a time.                                                                                                    */
 size_t ganq_lut_linear_workspace_bytes(int64_t M, int64_t m, int64_t n, int bits);
+int ganq_lut_linear_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, const void* bias, int dtype,
                         int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace, size_t workspace_bytes,
                         void* stream);

@@ -106,11 +106,14 @@ def test_pack_roundtrip_and_layout(hip, bits):
     assert np.array_equal(qw.cpu().numpy().view(np.uint32), ref.astype(np.uint32))
 
 
-@pytest.mark.parametrize("bits,M,dtype", [(4, 1, torch.float16), (4, 5, torch.float16), (3, 2, torch.bfloat16),
-                                          (2, 8, torch.float16), (4, 16, torch.bfloat16)])
-def test_lut_linear_vs_dense(hip, oracle, bits, M, dtype):
+@pytest.mark.parametrize("bits,M,dtype,m,n", [(4, 1, torch.float16, 200, 512), (4, 5, torch.float16, 200, 512),
+                                              (3, 2, torch.bfloat16, 200, 512), (2, 8, torch.float16, 200, 512),
+                                              (4, 16, torch.bfloat16, 200, 512), (3, 17, torch.float16, 77, 2080),
+                                              (4, 33, torch.bfloat16, 45, 4128), (2, 64, torch.float16, 130, 1056),
+                                              (3, 1, torch.float16, 1, 32), (4, 64, torch.float16, 4096, 11008)])
+def test_lut_linear_vs_dense(hip, oracle, bits, M, dtype, m, n):
     rng = np.random.default_rng(bits * 100 + M)
-    m, n, V = 200, 512, 2 ** bits
+    V = 2 ** bits
     Q = rng.integers(0, V, size=(m, n), dtype=np.uint8)
     lut = torch.from_numpy((0.02 * rng.standard_normal((m, V))).astype(np.float32)).to(dtype)
     x = torch.from_numpy(rng.standard_normal((M, n)).astype(np.float32)).to(dtype)
@@ -126,6 +129,28 @@ def test_lut_linear_vs_dense(hip, oracle, bits, M, dtype):
     if dtype == torch.float16:
         yo = oracle.lut_linear(x.numpy(), Q, lut.numpy(), bias.numpy())
         assert np.allclose(y.float().numpy(), yo, rtol=eps, atol=eps * 0.05 * np.abs(yo).max() + 1e-6)
+
+
+def test_lut_linear_repeat_is_bitwise_stable(hip):
+    # split-K through ticket counters in a persistent workspace: every call must leave them clean, and the
+    # reduction order is fixed -> many calls, interleaved shapes, identical bits
+    rng = np.random.default_rng(7)
+    outs = {}
+    cases = [(4, 1, 4096, 4096), (3, 16, 1000, 2048), (4, 40, 300, 8192), (2, 3, 129, 64)]
+    data = {}
+    for bits, M, m, n in cases:
+        Q = rng.integers(0, 2 ** bits, size=(m, n), dtype=np.uint8)
+        data[(bits, M, m, n)] = (hip.pack_indices(dev(Q), bits),
+                                 torch.from_numpy((0.02 * rng.standard_normal((m, 2 ** bits))).astype(np.float32)).half().cuda(),
+                                 torch.from_numpy(rng.standard_normal((M, n)).astype(np.float32)).half().cuda())
+    for rep in range(25):
+        for key in cases:
+            qw, lut, x = data[key]
+            y = hip.lut_linear(x, qw, lut, None, key[0])
+            if rep == 0:
+                outs[key] = y.clone()
+            else:
+                assert torch.equal(y, outs[key]), (key, rep)
 
 
 def test_lut_linear_golden_forward(hip):

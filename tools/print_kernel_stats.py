@@ -1,0 +1,8 @@
+"""Print name / calls / average ns of the top rows of a rocprofv3 kernel_stats.csv (names cut short)."""
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+h = rows[0]
+ni, ci, ai = h.index("Name"), h.index("Calls"), h.index("AverageNs")
+for r in rows[1:1 + top]:
+    print(f"  {r[ni].split('(')[0][:70]:70s} calls={r[ci]:>6s} avg_us={float(r[ai]) / 1e3:9.2f}")
