@@ -37,24 +37,128 @@ __device__ __forceinline__ void km_better(double& bc, int& bj, double c, int j) 
     }
 }
 
-__global__ __launch_bounds__(256) void kmeans_kernel(const float* __restrict__ W, const double* __restrict__ col_weight,
-                                                     int m, int n, int V, int P, float* __restrict__ T0,
-                                                     char* __restrict__ ws, size_t ws_stride) {
+// ---- LDS-resident variant (n up to ~4.6k): the prefix sums and D[k-1] live in LDS as four fp64 arrays, the argmins of
+// the current layer as u16, one 1024-thread workgroup per row (persistent).  Same arithmetic, association order and
+// tie-breaks as kmeans_kernel; only where the operands live differs -- the global-memory variant spends its time waiting
+// on one dependent L2 round trip per candidate.
+constexpr int KL_THREADS = 1024;
+#ifndef KM_LONG
+#define KM_LONG 16  // measured on MI355X (4096x4096, V=16): 4 -> 30 ms, 8 -> 23 ms, 16 -> 19 ms, 48 -> 22 ms
+#endif
+#ifdef GANQ_KMEANS_DEBUG
+__device__ unsigned long long km_dbg[32];
+#define KM_STAMP(slot) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&km_dbg[slot], now_ - last_); last_ = now_; } } while (0)
+#else
+#define KM_STAMP(slot) do {} while (0)
+#endif
+
+__device__ __forceinline__ double km_cost4(double cwj, double cwxj, double cwxxj, double cw_i1, double cwx_i1, double cwxx_i1) {
+    const double w = cw_i1 - cwj;
+    const double wx = cwx_i1 - cwxj;
+    const double wxx = cwxx_i1 - cwxxj;
+    if (!(w > 0.0)) return 0.0;
+    const double c = wxx - (wx * wx) / w;
+    return c > 0.0 ? c : 0.0;
+}
+
+// Nodes t0..t1 of one level, G <= 64 lanes per node (G a power of two; tid/G indexes the node within a pass).
+// wcw.. are the operand arrays indexed by j - base, icw.. the same sums indexable by i + 1.
+// The argmin jumps at cluster boundaries, so a few nodes of a level have ranges hundreds of candidates long while
+// most have two or three: a node longer than KM_LONG*G candidates is left to the whole wave (64 lanes) right after the
+// pass, instead of stalling the 63 other lanes of its wave.  The minimum with its (cost, j) tie-break is
+// order-independent, so who scans what does not change the result.
+__device__ __forceinline__ void km_level_nodes(const double* wcw, const double* wcwx, const double* wcwxx, const double* wdp,
+                                               int base, const double* icw, const double* icwx, const double* icwxx,
+                                               uint16_t* acur, double* dcur, int* ag, int t0, int t1, int hs, int n, int G) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lg = tid & (G - 1);
+    const int groups = KL_THREADS / G;
+    for (int tw = t0 + (tid >> 6) * (64 / G); tw <= t1; tw += groups) {  // uniform per wave
+        const int t = tw + lane / G;
+        const bool valid = t <= t1;
+        int i = 0, lo = 0, hi = -1;
+        if (valid) {
+            i = hs - 1 + t * 2 * hs;
+            lo = (i - hs >= 0) ? (int)acur[i - hs] : 0;
+            const int right = (i + hs < n) ? (i + hs) : (n - 1);
+            hi = max(lo, min(i, (int)acur[right]));
+        }
+        const bool is_long = valid && (hi - lo + 1 > KM_LONG * G);
+        double bc = INFINITY;
+        int bj = 0x7fffffff;
+        if (valid && !is_long) {
+            const double ci = icw[i + 1], cxi = icwx[i + 1], cxxi = icwxx[i + 1];
+            for (int j = lo + lg; j <= hi; j += G) {
+                const int idx = j - base;
+                km_better(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
+            }
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            const double oc = __shfl_xor(bc, off);
+            const int oj = __shfl_xor(bj, off);
+            km_better(bc, bj, oc, oj);
+        }
+        if (valid && !is_long && lg == 0) {
+            dcur[i] = bc;
+            ag[i] = bj;
+            acur[i] = (uint16_t)bj;
+        }
+        uint64_t todo = __ballot(is_long && lg == 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int li = __builtin_amdgcn_readlane(i, src), llo = __builtin_amdgcn_readlane(lo, src),
+                      lhi = __builtin_amdgcn_readlane(hi, src);
+            const double ci = icw[li + 1], cxi = icwx[li + 1], cxxi = icwxx[li + 1];
+            double c2 = INFINITY;
+            int j2 = 0x7fffffff;
+            for (int j = llo + lane; j <= lhi; j += 64) {
+                const int idx = j - base;
+                km_better(c2, j2, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double oc = __shfl_xor(c2, off);
+                const int oj = __shfl_xor(j2, off);
+                km_better(c2, j2, oc, oj);
+            }
+            if (lane == 0) {
+                dcur[li] = c2;
+                ag[li] = j2;
+                acur[li] = (uint16_t)j2;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __restrict__ W, const double* __restrict__ col_weight,
+                                                                int m, int n, int V, int P, float* __restrict__ T0,
+                                                                char* __restrict__ ws, size_t ws_stride) {
     extern __shared__ __align__(16) char km_smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(km_smem);  // [P]
-    __shared__ double red_c[4];
-    __shared__ int red_j[4];
-    __shared__ double chunk_tot[3][1024];  // chunk totals (n <= 16384 -> <= 1024 chunks)
+    const int n1 = n + 1;
+    double* cw = reinterpret_cast<double*>(km_smem);
+    double* cwx = cw + n1;
+    double* cwxx = cwx + n1;
+    double* dprev = cwxx + n1;
+    uint16_t* acur = reinterpret_cast<uint16_t*>(dprev + n1);  // [n] argmins of the layer being solved
+    uint64_t* keys = reinterpret_cast<uint64_t*>(km_smem);     // [P] during the sort only (8P <= 16(n+1): over cw, cwx)
+    double* ctot = dprev;                                       // [3][nchunk] during the prefix sums only
+    __shared__ double red_c[KL_THREADS / 64];
+    __shared__ int red_j[KL_THREADS / 64];
 
     const int tid = threadIdx.x;
     char* my = ws + (size_t)blockIdx.x * ws_stride;
-    KmPre* pre = reinterpret_cast<KmPre*>(my);                                               // [n+1]
-    double* dcur = reinterpret_cast<double*>(my + align_up((size_t)(n + 1) * sizeof(KmPre), 256));  // [n]
-    int* arg = reinterpret_cast<int*>(reinterpret_cast<char*>(dcur) + align_up((size_t)n * sizeof(double), 256));  // [V][n]
+    double* xs = reinterpret_cast<double*>(my);  // [n] sorted values
+    double* wts = xs + n;                        // [n] their weights
+    double* dcur = wts + n;                      // [n] D[k] of the layer being solved
+    int* arg = reinterpret_cast<int*>(dcur + n); // [V][n]
+    const int nchunk = (n + KM_CHUNK - 1) / KM_CHUNK;
 
     for (int row = blockIdx.x; row < m; row += gridDim.x) {
+#ifdef GANQ_KMEANS_DEBUG
+        unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
         // ---- 1. sort ------------------------------------------------------------------------------
-        for (int i = tid; i < P; i += 256) {
+        for (int i = tid; i < P; i += KL_THREADS) {
             uint64_t key = ~0ull;
             if (i < n) {
                 uint32_t b = __builtin_bit_cast(uint32_t, W[(int64_t)row * n + i]);
@@ -66,7 +170,7 @@ __global__ __launch_bounds__(256) void kmeans_kernel(const float* __restrict__ W
         __syncthreads();
         for (int k = 2; k <= P; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P; i += 256) {
+                for (int i = tid; i < P; i += KL_THREADS) {
                     const int partner = i ^ j;
                     if (partner > i) {
                         const bool asc = (i & k) == 0;
@@ -80,83 +184,317 @@ __global__ __launch_bounds__(256) void kmeans_kernel(const float* __restrict__ W
                 __syncthreads();
             }
         }
-        auto val_at = [&](int u) -> double {
-            uint32_t b = (uint32_t)(keys[u] >> 32);
+        for (int u = tid; u < n; u += KL_THREADS) {
+            const uint64_t key = keys[u];
+            uint32_t b = (uint32_t)(key >> 32);
             b ^= (b >> 31) ? 0x80000000u : 0xffffffffu;
-            return (double)__builtin_bit_cast(float, b);
-        };
-        auto wt_at = [&](int u) -> double { return col_weight ? col_weight[(uint32_t)keys[u]] : 1.0; };
+            xs[u] = (double)__builtin_bit_cast(float, b);
+            wts[u] = col_weight ? col_weight[(uint32_t)key] : 1.0;
+        }
+        __syncthreads();
 
+        KM_STAMP(0);
         // ---- 2. prefix sums (chunks of 16, then chunk totals, both left to right) ----------------------
-        const int nchunk = (n + KM_CHUNK - 1) / KM_CHUNK;
-        for (int c = tid; c < nchunk; c += 256) {
+        for (int c = tid; c < nchunk; c += KL_THREADS) {
             double a = 0.0, b = 0.0, d = 0.0;
             const int hi = min(n, (c + 1) * KM_CHUNK);
             for (int u = c * KM_CHUNK; u < hi; ++u) {
-                const double x = val_at(u), w = wt_at(u);
+                const double x = xs[u], w = wts[u];
                 a += w;
                 b += w * x;
                 d += w * x * x;
             }
-            chunk_tot[0][c] = a;
-            chunk_tot[1][c] = b;
-            chunk_tot[2][c] = d;
+            ctot[c] = a;
+            ctot[nchunk + c] = b;
+            ctot[2 * nchunk + c] = d;
         }
         __syncthreads();
-        if (tid < 3) {
+        if ((tid & 63) == 0 && (tid >> 6) < 3) {  // three waves, one lane each
+            double* ct = ctot + (tid >> 6) * nchunk;
             double run = 0.0;
             for (int c = 0; c < nchunk; ++c) {
-                const double t = chunk_tot[tid][c];
-                chunk_tot[tid][c] = run;  // exclusive
+                const double t = ct[c];
+                ct[c] = run;  // exclusive
                 run += t;
             }
         }
         __syncthreads();
-        for (int c = tid; c < nchunk; c += 256) {
+        for (int c = tid; c < nchunk; c += KL_THREADS) {
             double a = 0.0, b = 0.0, d = 0.0;
-            const double oa = chunk_tot[0][c], ob = chunk_tot[1][c], od = chunk_tot[2][c];
+            const double oa = ctot[c], ob = ctot[nchunk + c], od = ctot[2 * nchunk + c];
             const int hi = min(n, (c + 1) * KM_CHUNK);
             for (int u = c * KM_CHUNK; u < hi; ++u) {
-                pre[u].cw = oa + a;
-                pre[u].cwx = ob + b;
-                pre[u].cwxx = od + d;
-                const double x = val_at(u), w = wt_at(u);
+                cw[u] = oa + a;
+                cwx[u] = ob + b;
+                cwxx[u] = od + d;
+                const double x = xs[u], w = wts[u];
                 a += w;
                 b += w * x;
                 d += w * x * x;
             }
             if (hi == n) {
-                pre[n].cw = oa + a;
-                pre[n].cwx = ob + b;
-                pre[n].cwxx = od + d;
-                pre[n].dprev = 0.0;
+                cw[n] = oa + a;
+                cwx[n] = ob + b;
+                cwxx[n] = od + d;
+            }
+        }
+        __syncthreads();
+
+        KM_STAMP(1);
+        // ---- 3. DP ----------------------------------------------------------------------------------------
+        for (int i = tid; i < n; i += KL_THREADS) {
+            dcur[i] = km_cost4(cw[0], cwx[0], cwxx[0], cw[i + 1], cwx[i + 1], cwxx[i + 1]);
+            arg[i] = 0;
+        }
+        __syncthreads();
+        for (int k = 1; k < V; ++k) {
+            for (int j = tid; j <= n; j += KL_THREADS) dprev[j] = (j == 0) ? 0.0 : dcur[j - 1];
+            __syncthreads();
+            KM_STAMP(2);
+            int* ag = arg + (size_t)k * n;
+            {   // position n-1: full scan by the whole workgroup
+                const int i = n - 1;
+                const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
+                double bc = INFINITY;
+                int bj = 0x7fffffff;
+                for (int j = tid; j <= i; j += KL_THREADS)
+                    km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double oc = __shfl_xor(bc, off);
+                    const int oj = __shfl_xor(bj, off);
+                    km_better(bc, bj, oc, oj);
+                }
+                if ((tid & 63) == 0) {
+                    red_c[tid >> 6] = bc;
+                    red_j[tid >> 6] = bj;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int w = 1; w < KL_THREADS / 64; ++w) km_better(bc, bj, red_c[w], red_j[w]);
+                    dcur[i] = bc;
+                    ag[i] = bj;
+                    acur[i] = (uint16_t)bj;
+                }
+                __syncthreads();
+            }
+            KM_STAMP(3);
+            if (k == V - 1) break;  // only D[V-1][n-1] is needed from the last layer
+            for (int hs = P >> 1; hs >= 1; hs >>= 1) {
+                const int cnt = (n - 1 > hs - 1) ? ((n - 1 - (hs - 1) + 2 * hs - 1) / (2 * hs)) : 0;
+                if (cnt == 0) continue;
+                int G = 1;
+                while (G < KL_THREADS && G * 2 * cnt <= KL_THREADS) G <<= 1;
+                const int lg = tid & (G - 1);
+                if (G <= 64) {
+                    km_level_nodes(cw, cwx, cwxx, dprev, 0, cw, cwx, cwxx, acur, dcur, ag, 0, cnt - 1, hs, n, G);
+                    __syncthreads();
+                } else {
+                    // few nodes: several waves per node, partial minima through LDS
+                    const int t = tid / G;
+                    const int i = hs - 1 + t * 2 * hs;
+                    double bc = INFINITY;
+                    int bj = 0x7fffffff;
+                    if (t < cnt) {
+                        const int lo = (i - hs >= 0) ? (int)acur[i - hs] : 0;
+                        const int right = (i + hs < n) ? (i + hs) : (n - 1);
+                        const int hi = max(lo, min(i, (int)acur[right]));
+                        const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
+                        for (int j = lo + lg; j <= hi; j += G)
+                            km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+                    }
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const double oc = __shfl_xor(bc, off);
+                        const int oj = __shfl_xor(bj, off);
+                        km_better(bc, bj, oc, oj);
+                    }
+                    if ((tid & 63) == 0) {
+                        red_c[tid >> 6] = bc;
+                        red_j[tid >> 6] = bj;
+                    }
+                    __syncthreads();
+                    if (lg == 0 && t < cnt) {
+                        const int w0 = tid >> 6;
+                        for (int w = 1; w < G / 64; ++w) km_better(bc, bj, red_c[w0 + w], red_j[w0 + w]);
+                        dcur[i] = bc;
+                        ag[i] = bj;
+                        acur[i] = (uint16_t)bj;
+                    }
+                    __syncthreads();
+                }
+                KM_STAMP(4 + (31 - __builtin_clz(hs)));
+            }
+        }
+
+        // ---- 4. backtrack + centroids ------------------------------------------------------------------------
+        if (tid == 0) {
+            int end = n - 1;
+            float* out = T0 + (int64_t)row * V;
+            for (int k = V - 1; k >= 0; --k) {
+                int start = (end >= 0) ? arg[(size_t)k * n + end] : 0;
+                if (k == 0) start = 0;
+                if (end >= start && end >= 0) {
+                    const double sw = cw[end + 1] - cw[start];
+                    const double swx = cwx[end + 1] - cwx[start];
+                    out[k] = (float)(sw > 0.0 ? swx / sw : xs[start]);
+                } else {
+                    out[k] = (k + 1 < V) ? out[k + 1] : (float)xs[n - 1];
+                }
+                end = start - 1;
+            }
+        }
+        KM_STAMP(20);
+        __syncthreads();
+    }
+}
+
+// ---- windowed variant (any n <= 16384): prefix sums and D[k] live in global memory (L2); every level walks its nodes
+// in segments whose candidate window [lo(first), hi(last)] fits the LDS window, stages the four operand arrays of
+// that window, and then works exactly like the resident variant.  A node whose own range is longer than the window
+// (top levels, and the full scan at i = n-1) is scanned by the whole workgroup piece by piece.
+__global__ __launch_bounds__(KL_THREADS) void kmeans_win_kernel(const float* __restrict__ W, const double* __restrict__ col_weight,
+                                                                int m, int n, int V, int P, int Wcap, float* __restrict__ T0,
+                                                                char* __restrict__ ws, size_t ws_stride) {
+    extern __shared__ __align__(16) char km_smem[];
+    double* wcw = reinterpret_cast<double*>(km_smem);  // window copies, index j - base
+    double* wcwx = wcw + Wcap;
+    double* wcwxx = wcwx + Wcap;
+    double* wdp = wcwxx + Wcap;
+    uint16_t* acur = reinterpret_cast<uint16_t*>(wdp + Wcap);  // [n]
+    uint64_t* keys = reinterpret_cast<uint64_t*>(km_smem);     // [P] during the sort only (may run over acur)
+    double* ctot = reinterpret_cast<double*>(km_smem);         // [3][nchunk] during the prefix sums only
+    __shared__ double red_c[KL_THREADS / 64];
+    __shared__ int red_j[KL_THREADS / 64];
+
+    const int tid = threadIdx.x;
+    const int n1 = n + 1;
+    char* my = ws + (size_t)blockIdx.x * ws_stride;
+    double* xs = reinterpret_cast<double*>(my);  // [n] sorted values
+    double* wts = xs + n;                        // [n] their weights
+    double* cw = wts + n;                        // [n+1] prefix sums
+    double* cwx = cw + n1;
+    double* cwxx = cwx + n1;
+    double* dbuf0 = cwxx + n1;                   // [n] D of even layers
+    double* dbuf1 = dbuf0 + n;                   // [n] D of odd layers
+    int* arg = reinterpret_cast<int*>(dbuf1 + n);  // [V][n]
+    const int nchunk = (n + KM_CHUNK - 1) / KM_CHUNK;
+
+    for (int row = blockIdx.x; row < m; row += gridDim.x) {
+        // ---- 1. sort ------------------------------------------------------------------------------
+        for (int i = tid; i < P; i += KL_THREADS) {
+            uint64_t key = ~0ull;
+            if (i < n) {
+                uint32_t b = __builtin_bit_cast(uint32_t, W[(int64_t)row * n + i]);
+                b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
+                key = ((uint64_t)b << 32) | (uint32_t)i;
+            }
+            keys[i] = key;
+        }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P; i += KL_THREADS) {
+                    const int partner = i ^ j;
+                    if (partner > i) {
+                        const bool asc = (i & k) == 0;
+                        const uint64_t a = keys[i], b = keys[partner];
+                        if ((a > b) == asc) {
+                            keys[i] = b;
+                            keys[partner] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int u = tid; u < n; u += KL_THREADS) {
+            const uint64_t key = keys[u];
+            uint32_t b = (uint32_t)(key >> 32);
+            b ^= (b >> 31) ? 0x80000000u : 0xffffffffu;
+            xs[u] = (double)__builtin_bit_cast(float, b);
+            wts[u] = col_weight ? col_weight[(uint32_t)key] : 1.0;
+        }
+        __syncthreads();
+
+        // ---- 2. prefix sums (chunks of 16, then chunk totals, both left to right) ----------------------
+        for (int c = tid; c < nchunk; c += KL_THREADS) {
+            double a = 0.0, b = 0.0, d = 0.0;
+            const int hi = min(n, (c + 1) * KM_CHUNK);
+            for (int u = c * KM_CHUNK; u < hi; ++u) {
+                const double x = xs[u], w = wts[u];
+                a += w;
+                b += w * x;
+                d += w * x * x;
+            }
+            ctot[c] = a;
+            ctot[nchunk + c] = b;
+            ctot[2 * nchunk + c] = d;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0 && (tid >> 6) < 3) {
+            double* ct = ctot + (tid >> 6) * nchunk;
+            double run = 0.0;
+            for (int c = 0; c < nchunk; ++c) {
+                const double t = ct[c];
+                ct[c] = run;  // exclusive
+                run += t;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < nchunk; c += KL_THREADS) {
+            double a = 0.0, b = 0.0, d = 0.0;
+            const double oa = ctot[c], ob = ctot[nchunk + c], od = ctot[2 * nchunk + c];
+            const int hi = min(n, (c + 1) * KM_CHUNK);
+            for (int u = c * KM_CHUNK; u < hi; ++u) {
+                cw[u] = oa + a;
+                cwx[u] = ob + b;
+                cwxx[u] = od + d;
+                const double x = xs[u], w = wts[u];
+                a += w;
+                b += w * x;
+                d += w * x * x;
+            }
+            if (hi == n) {
+                cw[n] = oa + a;
+                cwx[n] = ob + b;
+                cwxx[n] = od + d;
             }
         }
         __syncthreads();
 
         // ---- 3. DP ----------------------------------------------------------------------------------------
-        // layer 0: D[0][i] = cost(0..i)
-        for (int i = tid; i < n; i += 256) {
-            const KmPre p0 = pre[0];
-            const KmPre pi = pre[i + 1];
-            dcur[i] = km_cost(p0, pi.cw, pi.cwx, pi.cwxx);
-            arg[i] = 0;
+        {
+            const double c0 = cw[0], cx0 = cwx[0], cxx0 = cwxx[0];
+            for (int i = tid; i < n; i += KL_THREADS) {
+                dbuf0[i] = km_cost4(c0, cx0, cxx0, cw[i + 1], cwx[i + 1], cwxx[i + 1]);
+                arg[i] = 0;
+            }
         }
         __syncthreads();
         for (int k = 1; k < V; ++k) {
-            // D[k-1] -> pre[j].dprev = D[k-1][j-1]
-            for (int j = tid; j <= n; j += 256) pre[j].dprev = (j == 0) ? 0.0 : dcur[j - 1];
-            __syncthreads();
-            int* a = arg + (size_t)k * n;
-            // position n-1: full scan by the whole workgroup
-            {
-                const int i = n - 1;
-                const KmPre pi = pre[i + 1];
+            const double* dprev_g = (k & 1) ? dbuf0 : dbuf1;  // D[k-1]
+            double* dcur = (k & 1) ? dbuf1 : dbuf0;
+            int* ag = arg + (size_t)k * n;
+            auto stage = [&](int base, int len) {  // window := [base, base+len)
+                for (int idx = tid; idx < len; idx += KL_THREADS) {
+                    const int j = base + idx;
+                    wcw[idx] = cw[j];
+                    wcwx[idx] = cwx[j];
+                    wcwxx[idx] = cwxx[j];
+                    wdp[idx] = (j == 0) ? 0.0 : dprev_g[j - 1];
+                }
+            };
+            // one node scanned by the whole workgroup, window piece by window piece
+            auto solve_wide = [&](int i, int lo, int hi) {
+                const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
                 double bc = INFINITY;
                 int bj = 0x7fffffff;
-                for (int j = tid; j <= i; j += 256) {
-                    const KmPre pj = pre[j];
-                    km_better(bc, bj, pj.dprev + km_cost(pj, pi.cw, pi.cwx, pi.cwxx), j);
+                for (int pb = lo; pb <= hi; pb += Wcap) {
+                    const int len = min(Wcap, hi - pb + 1);
+                    stage(pb, len);
+                    __syncthreads();
+                    for (int idx = tid; idx < len; idx += KL_THREADS)
+                        km_better(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), pb + idx);
+                    __syncthreads();
                 }
                 for (int off = 32; off > 0; off >>= 1) {
                     const double oc = __shfl_xor(bc, off);
@@ -169,44 +507,87 @@ __global__ __launch_bounds__(256) void kmeans_kernel(const float* __restrict__ W
                 }
                 __syncthreads();
                 if (tid == 0) {
-                    for (int w = 1; w < 4; ++w) km_better(bc, bj, red_c[w], red_j[w]);
+                    for (int w = 1; w < KL_THREADS / 64; ++w) km_better(bc, bj, red_c[w], red_j[w]);
                     dcur[i] = bc;
-                    a[i] = bj;
+                    ag[i] = bj;
+                    acur[i] = (uint16_t)bj;
                 }
                 __syncthreads();
-            }
+            };
+            solve_wide(n - 1, 0, n - 1);
             if (k == V - 1) break;  // only D[V-1][n-1] is needed from the last layer
             for (int hs = P >> 1; hs >= 1; hs >>= 1) {
-                // nodes i = hs-1 + t*2hs, i < n-1
                 const int cnt = (n - 1 > hs - 1) ? ((n - 1 - (hs - 1) + 2 * hs - 1) / (2 * hs)) : 0;
-                if (cnt == 0) continue;
-                int G = 1;
-                while (G < 64 && G * 2 * cnt <= 256) G <<= 1;
-                const int groups = 256 / G;
-                const int lg = tid & (G - 1);
-                for (int t = tid / G; t < cnt; t += groups) {
+                auto node_lo = [&](int t) {
                     const int i = hs - 1 + t * 2 * hs;
-                    const int lo = (i - hs >= 0) ? a[i - hs] : 0;
+                    return (i - hs >= 0) ? (int)acur[i - hs] : 0;
+                };
+                auto node_hi = [&](int t) {
+                    const int i = hs - 1 + t * 2 * hs;
                     const int right = (i + hs < n) ? (i + hs) : (n - 1);
-                    const int hi = max(lo, min(i, a[right]));
-                    const KmPre pi = pre[i + 1];
-                    double bc = INFINITY;
-                    int bj = 0x7fffffff;
-                    for (int j = lo + lg; j <= hi; j += G) {
-                        const KmPre pj = pre[j];
-                        km_better(bc, bj, pj.dprev + km_cost(pj, pi.cw, pi.cwx, pi.cwxx), j);
+                    return max(node_lo(t), min(i, (int)acur[right]));
+                };
+                int t0 = 0;
+                while (t0 < cnt) {  // every quantity below is uniform over the workgroup
+                    const int base = node_lo(t0);
+                    if (node_hi(t0) - base + 1 > Wcap) {
+                        solve_wide(hs - 1 + t0 * 2 * hs, base, node_hi(t0));
+                        ++t0;
+                        continue;
                     }
-                    for (int off = G >> 1; off > 0; off >>= 1) {
-                        const double oc = __shfl_xor(bc, off);
-                        const int oj = __shfl_xor(bj, off);
-                        km_better(bc, bj, oc, oj);
+                    int t1 = t0;  // last node of the segment: largest t with hi(t) < base + Wcap (hi is non-decreasing)
+                    for (int lo_t = t0, hi_t = cnt - 1; lo_t <= hi_t;) {
+                        const int mid = (lo_t + hi_t) >> 1;
+                        if (node_hi(mid) - base + 1 <= Wcap) {
+                            t1 = mid;
+                            lo_t = mid + 1;
+                        } else {
+                            hi_t = mid - 1;
+                        }
                     }
-                    if (lg == 0) {
-                        dcur[i] = bc;
-                        a[i] = bj;
+                    const int segcnt = t1 - t0 + 1;
+                    stage(base, node_hi(t1) - base + 1);
+                    __syncthreads();
+                    int G = 1;
+                    while (G < KL_THREADS && G * 2 * segcnt <= KL_THREADS) G <<= 1;
+                    const int lg = tid & (G - 1);
+                    if (G <= 64) {
+                        km_level_nodes(wcw, wcwx, wcwxx, wdp, base, cw, cwx, cwxx, acur, dcur, ag, t0, t1, hs, n, G);
+                        __syncthreads();
+                    } else {
+                        const int t = t0 + tid / G;
+                        const int i = hs - 1 + t * 2 * hs;
+                        double bc = INFINITY;
+                        int bj = 0x7fffffff;
+                        if (t <= t1) {
+                            const int lo = node_lo(t), hi = node_hi(t);
+                            const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
+                            for (int j = lo + lg; j <= hi; j += G) {
+                                const int idx = j - base;
+                                km_better(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
+                            }
+                        }
+                        for (int off = 32; off > 0; off >>= 1) {
+                            const double oc = __shfl_xor(bc, off);
+                            const int oj = __shfl_xor(bj, off);
+                            km_better(bc, bj, oc, oj);
+                        }
+                        if ((tid & 63) == 0) {
+                            red_c[tid >> 6] = bc;
+                            red_j[tid >> 6] = bj;
+                        }
+                        __syncthreads();
+                        if (lg == 0 && t <= t1) {
+                            const int w0 = tid >> 6;
+                            for (int w = 1; w < G / 64; ++w) km_better(bc, bj, red_c[w0 + w], red_j[w0 + w]);
+                            dcur[i] = bc;
+                            ag[i] = bj;
+                            acur[i] = (uint16_t)bj;
+                        }
+                        __syncthreads();
                     }
+                    t0 = t1 + 1;
                 }
-                __syncthreads();
             }
         }
 
@@ -218,11 +599,11 @@ __global__ __launch_bounds__(256) void kmeans_kernel(const float* __restrict__ W
                 int start = (end >= 0) ? arg[(size_t)k * n + end] : 0;
                 if (k == 0) start = 0;
                 if (end >= start && end >= 0) {
-                    const double sw = pre[end + 1].cw - pre[start].cw;
-                    const double swx = pre[end + 1].cwx - pre[start].cwx;
-                    out[k] = (float)(sw > 0.0 ? swx / sw : val_at(start));
+                    const double sw = cw[end + 1] - cw[start];
+                    const double swx = cwx[end + 1] - cwx[start];
+                    out[k] = (float)(sw > 0.0 ? swx / sw : xs[start]);
                 } else {
-                    out[k] = (k + 1 < V) ? out[k + 1] : (float)val_at(n - 1);
+                    out[k] = (k + 1 < V) ? out[k + 1] : (float)xs[n - 1];
                 }
                 end = start - 1;
             }
@@ -231,11 +612,37 @@ __global__ __launch_bounds__(256) void kmeans_kernel(const float* __restrict__ W
     }
 }
 
-static size_t kmeans_stride(int64_t n, int V) {
-    return align_up((size_t)(n + 1) * sizeof(KmPre), 256) + align_up((size_t)n * sizeof(double), 256) +
-           align_up((size_t)V * (size_t)n * sizeof(int), 256);
+struct KmPlan {
+    bool lds;
+    int grid, P, Wcap;
+    size_t smem, stride;
+};
+constexpr size_t KM_LDS_BUDGET = 160 * 1024 - 1024;  // dynamic part; the rest covers the static reduction slots
+static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
+    KmPlan p;
+    p.P = 1;
+    while (p.P < n) p.P <<= 1;
+    p.Wcap = 0;
+    const size_t acur_bytes = align_up((size_t)n * sizeof(uint16_t), 16);
+    const size_t lds_bytes = 4 * (size_t)(n + 1) * sizeof(double) + acur_bytes;
+    p.lds = lds_bytes <= KM_LDS_BUDGET;
+    const char* force = getenv("GANQ_KMEANS_WCAP");  // testing: force the windowed kernel with a small window
+    const int forced = force ? atoi(force) : 0;
+    if (forced > 0) p.lds = false;
+    if (p.lds) {
+        p.smem = lds_bytes;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (KM_LDS_BUDGET + 1024) / (lds_bytes + 1024)));
+        p.grid = (int)std::min<int64_t>(m, 256 * per_cu);
+        p.stride = align_up(3 * (size_t)n * sizeof(double) + (size_t)V * (size_t)n * sizeof(int), 256);
+    } else {
+        p.Wcap = (int)((KM_LDS_BUDGET - acur_bytes) / (4 * sizeof(double))) & ~63;
+        if (forced > 0) p.Wcap = std::min(p.Wcap, forced);
+        p.smem = std::max((size_t)p.P * sizeof(uint64_t), 4 * (size_t)p.Wcap * sizeof(double) + acur_bytes);
+        p.grid = (int)std::min<int64_t>(m, 256);
+        p.stride = align_up((4 * (size_t)n + 3 * (size_t)(n + 1)) * sizeof(double) + (size_t)V * (size_t)n * sizeof(int), 256);
+    }
+    return p;
 }
-static int kmeans_grid(int64_t m) { return (int)std::min<int64_t>(m, 1024); }
 
 }  // namespace ganq
 
@@ -243,7 +650,8 @@ using namespace ganq;
 
 extern "C" size_t ganq_kmeans_workspace_bytes(int64_t m, int64_t n, int V) {
     if (m <= 0 || n <= 0 || V <= 0) return 0;
-    return (size_t)kmeans_grid(m) * kmeans_stride(n, V);
+    const KmPlan p = kmeans_plan(m, n, V);
+    return (size_t)p.grid * p.stride;
 }
 
 extern "C" int ganq_kmeans_init(const float* W, const double* col_weight, int64_t m, int64_t n, int V, float* T0,
@@ -253,22 +661,34 @@ extern "C" int ganq_kmeans_init(const float* W, const double* col_weight, int64_
     if (n < 1 || V < 1 || V > 256) return fail(-2, "ganq_kmeans_init: bad n=%lld / V=%d", (long long)n, V);
     if (n > 16384) return fail(-2, "ganq_kmeans_init: n=%lld > 16384 not supported (LDS sort)", (long long)n);
     if (!W || !T0) return fail(-3, "ganq_kmeans_init: null pointer");
-    const size_t need = ganq_kmeans_workspace_bytes(m, n, V);
+    const KmPlan p = kmeans_plan(m, n, V);
+    const size_t need = (size_t)p.grid * p.stride;
     if (!workspace || workspace_bytes < need)
         return fail(-4, "ganq_kmeans_init: workspace %zu B < required %zu B", workspace_bytes, need);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    int P = 1;
-    while (P < n) P <<= 1;
-    const size_t smem = (size_t)P * sizeof(uint64_t);
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_smem = smem;
+    static size_t attr_smem[2] = {0, 0};
+    if (p.smem > attr_smem[p.lds]) {
+        const void* fn = p.lds ? reinterpret_cast<const void*>(kmeans_lds_kernel) : reinterpret_cast<const void*>(kmeans_win_kernel);
+        GANQ_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
+        attr_smem[p.lds] = p.smem;
     }
     ProfScope prof(KID_KMEANS, stream);
-    hipLaunchKernelGGL(kmeans_kernel, dim3(kmeans_grid(m)), dim3(256), smem, stream, W, col_weight, (int)m, (int)n, V, P, T0,
-                       static_cast<char*>(workspace), kmeans_stride(n, V));
+    if (p.lds)
+        hipLaunchKernelGGL(kmeans_lds_kernel, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n, V, p.P,
+                           T0, static_cast<char*>(workspace), p.stride);
+    else
+        hipLaunchKernelGGL(kmeans_win_kernel, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n, V,
+                           p.P, p.Wcap, T0, static_cast<char*>(workspace), p.stride);
     GANQ_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef GANQ_KMEANS_DEBUG
+extern "C" int ganq_debug_kmeans_cycles(unsigned long long* out32) {
+    GANQ_HIP_CHECK(hipDeviceSynchronize());
+    GANQ_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(ganq::km_dbg), 32 * sizeof(unsigned long long)));
+    unsigned long long z[32] = {0};
+    GANQ_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ganq::km_dbg), z, sizeof(z)));
+    return 0;
+}
+#endif

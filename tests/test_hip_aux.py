@@ -65,7 +65,8 @@ def test_hessian_vs_oracle_shapes(hip, oracle, rows, n, dtype):
 
 
 # ------------------------------------------------------------------------------------------ k-means
-@pytest.mark.parametrize("m,n,V,seed", [(8, 64, 4, 1), (32, 300, 16, 2), (16, 1024, 8, 3), (5, 4096, 16, 4), (3, 17, 16, 5)])
+@pytest.mark.parametrize("m,n,V,seed", [(8, 64, 4, 1), (32, 300, 16, 2), (16, 1024, 8, 3), (5, 4096, 16, 4), (3, 17, 16, 5),
+                                        (700, 256, 16, 6), (2, 4700, 16, 7), (2, 4800, 16, 8), (3, 1, 4, 9), (2, 2, 4, 10)])
 def test_kmeans_vs_oracle(hip, oracle, m, n, V, seed):
     rng = np.random.default_rng(seed)
     W = (0.02 * rng.standard_normal((m, n))).astype(np.float16).astype(np.float32)
@@ -74,6 +75,20 @@ def test_kmeans_vs_oracle(hip, oracle, m, n, V, seed):
     ref = oracle.kmeans_init(W, wts, V)
     assert rel_fro(T0, ref) < 1e-6, np.abs(T0 - ref).max()
     assert np.all(np.diff(T0, axis=1) >= 0)
+
+
+@pytest.mark.parametrize("wcap", [64, 200, 1024])
+def test_kmeans_windowed_kernel_small_windows(hip, oracle, wcap, monkeypatch):
+    # the large-n kernel (prefix sums in L2, LDS window per segment of nodes) forced onto small rows with a tiny window:
+    # exercises multi-segment levels and nodes wider than the window
+    monkeypatch.setenv("GANQ_KMEANS_WCAP", str(wcap))
+    rng = np.random.default_rng(wcap)
+    for m, n, V in [(6, 777, 16), (3, 2048, 8), (300, 130, 4)]:
+        W = (0.02 * rng.standard_normal((m, n))).astype(np.float16).astype(np.float32)
+        wts = rng.uniform(0.2, 3.0, n) ** -4
+        T0 = hip.kmeans_init(dev(W), torch.from_numpy(wts), V).cpu().numpy()
+        ref = oracle.kmeans_init(W, wts, V)
+        assert rel_fro(T0, ref) < 1e-6, (m, n, V, np.abs(T0 - ref).max())
 
 
 def test_kmeans_golden_T0(hip):
