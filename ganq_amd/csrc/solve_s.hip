@@ -2,7 +2,8 @@
 // kernel compute_s ganq.py:94-247).  Arithmetic contract: include/ganq_hip.h + oracle/ganq_oracle.c
 // (ganq_oracle_solve_s) -- bit-exact indices.
 //
-// Decomposition (one workgroup = 16 rows of W for the whole solve, no inter-workgroup traffic):
+// Decomposition (one workgroup = 16 rows of W for the whole solve, no inter-workgroup traffic; 8 waves in two roles,
+// see solve_s_kernel):
 //   columns are processed right-to-left in panels of 64.  For panel [j0, j0+64):
 //   (G) left-looking residual GEMM on the fp32 matrix cores: R[16, 64] = Err[16, j0+64:n] @ L[j0+64:n, j0:j0+64],
 //       one v_mfma_f32_16x16x4_f32 accumulation chain per output, k running over columns in
@@ -13,6 +14,7 @@
 //       triangle of L read from LDS.
 //   Err (= W - T[Q]) is kept in a per-tile transposed scratch ErrT[tile][col][16 rows] so that the
 //   A operand of (G) is one coalesced 256 B read.
+#include <type_traits>
 #include <utility>
 
 #include "common.h"
@@ -22,6 +24,7 @@ namespace ganq {
 constexpr int SB = 64;   // panel width (columns)
 constexpr int SR = 16;   // rows per workgroup
 constexpr int SPF = 16;  // k-groups per prefetch batch
+constexpr int SOLVE_LDS_COLS = 1792;  // columns of Err kept in LDS (112 KB next to the 46 KB of panel buffers)
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t x) {
@@ -98,22 +101,42 @@ __device__ __forceinline__ void panel_all(PanelState& st, const float4 (*Ld)[16]
     }
 }
 
-template <bool KASC>
-__global__ __launch_bounds__(256) void solve_s_kernel(const float* __restrict__ W, const float* __restrict__ L,
+// Two roles per workgroup (8 waves, one of each role per SIMD):
+//   waves 0-3 (P) run the sequential steps of panel b+1 while
+//   waves 4-7 (G) run the residual chain of panel b over every column right of panel b+1 (part 1); after the barrier
+//   the G waves append the 64 columns of panel b+1 (part 2: Err handed over in LDS, the L block prefetched into
+//   registers) and publish R for panel b.  The chain of an output is still ONE accumulator running over the columns
+//   in descending order -- only who computes when has changed.  G also stages the next panel's triangle of L and
+//   its diagonal (double-buffered), P prefetches its next W columns.
+#ifdef GANQ_SOLVE_DEBUG
+__device__ unsigned long long ss_dbg[8];
+#define SS_T() __builtin_amdgcn_s_memtime()
+#define SS_ADD(slot, t0, who) do { if (tid == (who)) atomicAdd(&ss_dbg[slot], __builtin_amdgcn_s_memtime() - (t0)); } while (0)
+#else
+#define SS_T() 0ull
+#define SS_ADD(slot, t0, who) do {} while (0)
+#endif
+template <bool KASC, int DBG = 0>
+__global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ W, const float* __restrict__ L,
                                                       int64_t ldl, const float* __restrict__ T, int m, int n, int V,
                                                       uint8_t* __restrict__ Q, float* __restrict__ ErrOut,
-                                                      float* __restrict__ ErrT) {
-    __shared__ float4 Ld[SB][16];      // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
-    __shared__ float Rp[SR][SB + 4];   // residual panel handed from (G) to (P)
-    __shared__ float2 Dg[SB];          // {L[j][j], 1 / L[j][j]} of the panel's columns
+                                                      float* __restrict__ ErrT, int cbase) {
+    __shared__ float4 Ld[2][SB][16];      // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
+    __shared__ float Rp[2][SR][SB + 4];   // residual panel handed from (G) to (P)
+    __shared__ float2 Dg[2][SB];          // {L[j][j], 1 / L[j][j]} of the panel's columns
+    __shared__ float ErrP[SB][SR];        // Err of the panel just solved, [col][row] (zero beyond the panel's width)
+    extern __shared__ __align__(16) float ErrL[];  // [n - cbase][SR]: Err of the columns >= cbase, the A operand's hot part
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool roleG = wv >= 4;
+    const int gw = wv & 3;
+    const int gtid = tid & 255;  // thread index inside the role
     const int tile = blockIdx.x;
     const int rsub = lane >> 4;
     const int c16 = lane & 15;
-    const int prow_in_tile = 4 * wv + rsub;  // row handled by this 16-lane group in phase (P)
+    const int prow_in_tile = 4 * gw + rsub;  // row handled by this 16-lane group in phase (P)
     const int prow = min(tile * SR + prow_in_tile, m - 1);
     const bool prow_ok = tile * SR + prow_in_tile < m;
     float* __restrict__ errt = ErrT + (int64_t)tile * n * SR;
@@ -121,112 +144,183 @@ __global__ __launch_bounds__(256) void solve_s_kernel(const float* __restrict__ 
     PanelState st;
     st.c16 = (uint32_t)c16;
     st.tv = (c16 < V) ? T[(int64_t)prow * V + c16] : __builtin_inff();
+    float wnext[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int ksub = lane >> 4;
+    const int kslot = KASC ? (3 - ksub) : ksub;  // column inside a k-group handled by this lane's MFMA slice
+    const uint32_t laneA = (uint32_t)(kslot * SR + c16);
 
     const int nb = (n + SB - 1) / SB;
-    for (int b = nb - 1; b >= 0; --b) {
-        const int j0 = b * SB;
-        const int wd = min(SB, n - j0);
-
-        // stage the panel's block of L into LDS
-#pragma unroll
-        for (int e = 0; e < (SB * SB) / 256; ++e) {
-            const int idx = e * 256 + tid;
-            const int jj = idx >> 6, col = idx & 63;
-            float v = 0.0f;
-            if (jj < wd && col < wd) v = L[(int64_t)(j0 + jj) * ldl + j0 + col];
-            reinterpret_cast<float*>(&Ld[jj][col & 15])[col >> 4] = v;
-        }
-        if (tid < SB) {
-            const float d = (tid < wd) ? L[(int64_t)(j0 + tid) * ldl + j0 + tid] : 1.0f;
-            Dg[tid] = make_float2(d, 1.0f / d);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int col = c16 + 16 * k;
-            st.w[k] = (col < wd) ? W[(int64_t)prow * n + j0 + col] : 0.0f;
-            st.q[k] = 0;
-            st.e[k] = 0.0f;
-        }
-
-        // ---- (G) residual GEMM: wave wv -> panel columns 16wv..16wv+15, all 16 rows -----------------
-        // k-group g covers columns 4g..4g+3; inside one MFMA the slice order follows the probed k order so that
-        // the chain always runs over columns in descending order.  Addresses are (uniform base) + (per-lane
-        // 32-bit offset): scalar pointer arithmetic, one VMEM instruction per operand.
+    for (int s = 0; s <= nb; ++s) {
+        const int bP = nb - s;      // panel solved in this step (none at s = 0)
+        const int bG = nb - 1 - s;  // panel whose residual is produced in this step (none at s = nb)
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        {
-            const int gbot = (j0 + SB) >> 2;
-            const int ksub = lane >> 4;
-            const int kslot = KASC ? (3 - ksub) : ksub;  // column inside the group handled by this lane's slice
-            const int colB = j0 + 16 * wv + c16;         // < n whenever there is any group (only the last panel is partial)
-            if ((n & 3) && (n >> 2) >= gbot) {           // ragged top group: columns >= n contribute nothing
-                const int u = 4 * (n >> 2) + kslot;
-                const bool ok = u < n;
-                const int uu = ok ? u : (n - 1);
-                const float av = errt[(int64_t)uu * SR + c16];
-                const float bv = L[(int64_t)uu * ldl + colB];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? av : 0.0f, ok ? bv : 0.0f, acc, 0, 0, 0);
-            }
-            const int gtop = (n >> 2) - 1;               // highest full group
-            const int nfull = gtop - gbot + 1;           // <= 0 for the last panel
-            const uint32_t laneA = (uint32_t)(kslot * SR + c16);
-            const uint32_t laneB = (uint32_t)kslot * (uint32_t)ldl + (uint32_t)colB;
-            auto load_batch = [&](int g0, float (&a)[SPF], float (&bb)[SPF]) {  // groups g0, g0-1, .., g0-SPF+1
+        float bpre[16];  // (G) L[(bG+1)*64 + 4g + kslot][colB], g = 0..15: the B operands of part 2
+        const unsigned long long t_step = SS_T();
+        if (!roleG) {
+            // ---- (P) ---------------------------------------------------------------------------------------
+            if (bP <= nb - 1) {
+                const int j0 = bP * SB;
+                const int wd = min(SB, n - j0);
 #pragma unroll
-                for (int i = 0; i < SPF; ++i) {
-                    const float* __restrict__ Ag = errt + (int64_t)(g0 - i) * (4 * SR);
-                    const float* __restrict__ Bg = L + (int64_t)(g0 - i) * 4 * ldl;
-                    a[i] = Ag[laneA];
-                    bb[i] = Bg[laneB];
+                for (int k = 0; k < 4; ++k) {
+                    st.w[k] = wnext[k];
+                    st.q[k] = 0;
+                    st.e[k] = 0.0f;
+                    st.r[k] = Rp[bP & 1][prow_in_tile][c16 + 16 * k];
                 }
-            };
-            float a0[SPF], b0[SPF], a1[SPF], b1[SPF];
-            int g = gtop;
-            int nbatch = nfull > 0 ? nfull / SPF : 0;
-            if (nbatch > 0) {
-                load_batch(g, a0, b0);
-                while (true) {
-                    if (nbatch > 1) load_batch(g - SPF, a1, b1);
+                if (bP >= 1) {
 #pragma unroll
-                    for (int i = 0; i < SPF; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[i], acc, 0, 0, 0);
-                    g -= SPF;
-                    if (--nbatch == 0) break;
-                    if (nbatch > 1) load_batch(g - SPF, a0, b0);
-#pragma unroll
-                    for (int i = 0; i < SPF; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], b1[i], acc, 0, 0, 0);
-                    g -= SPF;
-                    if (--nbatch == 0) break;
+                    for (int k = 0; k < 4; ++k) wnext[k] = W[(int64_t)prow * n + j0 - SB + c16 + 16 * k];  // full panel
                 }
-            }
-            for (; g >= gbot; --g) {  // fewer than SPF groups left
-                const float* __restrict__ Ag = errt + (int64_t)g * (4 * SR);
-                const float* __restrict__ Bg = L + (int64_t)g * 4 * ldl;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ag[laneA], Bg[laneB], acc, 0, 0, 0);
-            }
-        }
+                if (wd == SB) {
+                    panel_all<true>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
+                } else {
+                    panel_all<false>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
+                }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Rp[rsub * 4 + r][16 * wv + c16] = acc[r];
-        __syncthreads();
-
-        // ---- (P) the panel's sequential steps ---------------------------------------------------------
+                for (int k = 0; k < 4; ++k) {
+                    const int col = c16 + 16 * k;
+                    ErrP[col][prow_in_tile] = (col < wd) ? st.e[k] : 0.0f;
+                    if (col < wd && j0 >= cbase) ErrL[(j0 - cbase + col) * SR + prow_in_tile] = st.e[k];
+                    if (col < wd) {
+                        errt[(int64_t)(j0 + col) * SR + prow_in_tile] = st.e[k];
+                        if (prow_ok) {
+                            Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
+                            if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
+                        }
+                    }
+                }
+            } else {
+                const int j0 = (nb - 1) * SB;  // W of the first (possibly partial) panel
 #pragma unroll
-        for (int k = 0; k < 4; ++k) st.r[k] = Rp[prow_in_tile][c16 + 16 * k];
-        if (wd == SB) {
-            panel_all<true>(st, Ld, Dg, wd, std::make_integer_sequence<int, SB>{});
-        } else {
-            panel_all<false>(st, Ld, Dg, wd, std::make_integer_sequence<int, SB>{});
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int col = c16 + 16 * k;
-            if (col < wd) {
-                errt[(int64_t)(j0 + col) * SR + prow_in_tile] = st.e[k];
-                if (prow_ok) {
-                    Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
-                    if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
+                for (int k = 0; k < 4; ++k) {
+                    const int col = c16 + 16 * k;
+                    wnext[k] = (j0 + col < n) ? W[(int64_t)prow * n + j0 + col] : 0.0f;
                 }
             }
+        } else if (bG >= 0) {
+            // ---- (G) part 1: columns right of panel bG+1, descending ----------------------------------------
+            const int j0 = bG * SB;
+            const int wd = min(SB, n - j0);
+            const int colB = j0 + 16 * gw + c16;  // < n whenever a product with it is used
+            // prefetches for later in this step: the panel's own block of L, its diagonal, the B operands of part 2
+            float lpre[(SB * SB) / 256];
+#pragma unroll
+            for (int e = 0; e < (SB * SB) / 256; ++e) {
+                const int idx = e * 256 + gtid;
+                const int jj = idx >> 6, col = idx & 63;
+                lpre[e] = (jj < wd && col < wd) ? L[(int64_t)(j0 + jj) * ldl + j0 + col] : 0.0f;
+            }
+            float dpre = 1.0f;
+            if (gtid < SB && gtid < wd) dpre = L[(int64_t)(j0 + gtid) * ldl + j0 + gtid];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int u = j0 + SB + 4 * g + kslot;
+                bpre[g] = (u < n && colB < n) ? L[(int64_t)u * ldl + colB] : 0.0f;
+            }
+            {
+                const int gbot = (j0 + 2 * SB) >> 2;
+                if ((n & 3) && (n >> 2) >= gbot) {  // ragged top group: columns >= n contribute nothing
+                    const int u = 4 * (n >> 2) + kslot;
+                    const bool ok = u < n;
+                    const int uu = ok ? u : (n - 1);
+                    const float av = errt[(int64_t)uu * SR + c16];
+                    const float bv = L[(int64_t)uu * ldl + colB];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? av : 0.0f, ok ? bv : 0.0f, acc, 0, 0, 0);
+                }
+                const int gtop = (n >> 2) - 1;     // highest full group
+                const uint32_t laneB = (uint32_t)kslot * (uint32_t)ldl + (uint32_t)colB;
+                // One chain segment: groups ghi, ghi-1, .., glo (descending), A from LDS (columns >= cbase) or from the
+                // global transposed scratch.  Batches of SPF groups, operands loaded two batches ahead into three
+                // rotating register sets; every load is unconditional (indices clamped to the segment) so that the
+                // waits in the steady-state loop count exactly the loads still allowed in flight.
+                auto chain = [&](auto a_in_lds, int ghi, int glo) {
+                    constexpr bool ALDS = decltype(a_in_lds)::value;
+                    const int total = ghi - glo + 1;
+                    if (total <= 0) return;
+                    const int nbat = total / SPF;
+                    const float* __restrict__ Al = ErrL + (int64_t)laneA - (int64_t)cbase * SR;
+                    const int64_t bstride = 4 * ldl;  // floats between the B rows of consecutive groups
+                    auto ld = [&](int bi, float (&aa)[SPF], float (&bb)[SPF]) {
+                        // lowest group of the batch; everything else is a compile-time multiple of a stride above it
+                        const int glow = ghi - min(bi, nbat - 1) * SPF - (SPF - 1);
+                        const float* __restrict__ Bp = L + (int64_t)glow * bstride;          // uniform
+                        const float* __restrict__ Ap = ALDS ? Al + glow * (4 * SR) : errt + (int64_t)glow * (4 * SR) + laneA;
+#pragma unroll
+                        for (int i = 0; i < SPF; ++i) {
+                            if constexpr (DBG == 1) bb[i] = 1.0f + (float)bi;
+                            else bb[i] = Bp[laneB];
+                            Bp += bstride;
+                            if constexpr (DBG == 2) aa[i] = 1.0f + (float)bi;
+                            else aa[i] = Ap[i * (4 * SR)];
+                        }
+                    };
+                    auto mm = [&](const float (&aa)[SPF], const float (&bb)[SPF]) {
+#pragma unroll
+                        for (int i = SPF - 1; i >= 0; --i) {
+                            if constexpr (DBG == 3) acc[0] = fmaf(aa[i], bb[i], acc[0]);
+                            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[i], bb[i], acc, 0, 0, 0);
+                        }
+                    };
+                    if (nbat > 0) {
+                        float a0[SPF], b0[SPF], a1[SPF], b1[SPF], a2[SPF], b2[SPF];
+                        // sched_barrier: the scheduler must not sink a batch of loads towards its use two batches later
+                        ld(0, a0, b0);
+                        ld(1, a1, b1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        int bi = 0;
+                        while (true) {
+                            ld(bi + 2, a2, b2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mm(a0, b0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (++bi == nbat) break;
+                            ld(bi + 2, a0, b0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mm(a1, b1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (++bi == nbat) break;
+                            ld(bi + 2, a1, b1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mm(a2, b2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (++bi == nbat) break;
+                        }
+                    }
+                    for (int g = ghi - nbat * SPF; g >= glo; --g) {  // fewer than SPF groups left (ragged n only)
+                        const float bv = (L + (int64_t)g * 4 * ldl)[laneB];
+                        const float av = ALDS ? Al[g * (4 * SR)] : (errt + (int64_t)g * (4 * SR))[laneA];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    }
+                };
+                const int glds = max(gbot, cbase >> 2);  // lowest group whose Err columns live in LDS
+                chain(std::true_type{}, gtop, glds);
+                chain(std::false_type{}, min(gtop, glds - 1), gbot);
+            }
+#pragma unroll
+            for (int e = 0; e < (SB * SB) / 256; ++e) {
+                const int idx = e * 256 + gtid;
+                const int jj = idx >> 6, col = idx & 63;
+                reinterpret_cast<float*>(&Ld[bG & 1][jj][col & 15])[col >> 4] = lpre[e];
+            }
+            if (gtid < SB) Dg[bG & 1][gtid] = make_float2(dpre, 1.0f / dpre);
         }
-        __syncthreads();  // ErrT stores visible to the next panel's GEMM; Ld / Rp free for reuse
+        SS_ADD(0, t_step, 0);    // P work
+        SS_ADD(1, t_step, 256);  // G part 1
+        __syncthreads();  // panel bP solved (ErrP, ErrT visible); part 1 of panel bG done
+        SS_ADD(2, t_step, 0);    // step up to barrier A
+        if (roleG && bG >= 0) {
+            // ---- (G) part 2: the 64 columns of panel bG+1, descending; then publish R ------------------------
+            if (bG + 1 <= nb - 1) {
+#pragma unroll
+                for (int g = 15; g >= 0; --g)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ErrP[4 * g + kslot][c16], bpre[g], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Rp[bG & 1][rsub * 4 + r][16 * gw + c16] = acc[r];
+        }
+        __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrP free
     }
 }
 
@@ -259,14 +353,50 @@ extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const f
     if (rc) return rc;
     const int tiles = (int)((m + SR - 1) / SR);
     float* errt = static_cast<float*>(workspace);
+    // the top SOLVE_LDS_COLS columns of Err (the ones every later panel re-reads) stay in LDS
+    const int cbase = (int)std::max<int64_t>(0, (n - SOLVE_LDS_COLS + SB - 1) / SB * SB);
+    const size_t smem = (size_t)(n - cbase) * SR * sizeof(float);
+    static size_t attr_smem = 0;
+    if (smem > attr_smem) {
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_smem = smem;
+    }
     ProfScope prof(KID_SOLVE_S, stream);
+#ifdef GANQ_SOLVE_DEBUG
+    if (const char* dm = getenv("GANQ_SOLVE_DBG")) {
+        const int d = atoi(dm);
+#define GANQ_DBG_LAUNCH(D) hipLaunchKernelGGL((solve_s_kernel<true, D>), dim3(tiles), dim3(512), smem, stream, W, L, ldl, T, (int)m, (int)n, V, Q_out, Err_out, errt, cbase)
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (d == 1) GANQ_DBG_LAUNCH(1);
+        else if (d == 2) GANQ_DBG_LAUNCH(2);
+        else if (d == 3) GANQ_DBG_LAUNCH(3);
+        else GANQ_DBG_LAUNCH(0);
+        GANQ_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
     if (mfma_k_ascending()) {
-        hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(256), 0, stream, W, L, ldl, T, (int)m, (int)n, V,
-                           Q_out, Err_out, errt);
+        hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, T, (int)m, (int)n, V,
+                           Q_out, Err_out, errt, cbase);
     } else {
-        hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(256), 0, stream, W, L, ldl, T, (int)m, (int)n, V,
-                           Q_out, Err_out, errt);
+        hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, T, (int)m, (int)n, V,
+                           Q_out, Err_out, errt, cbase);
     }
     GANQ_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef GANQ_SOLVE_DEBUG
+extern "C" int ganq_debug_solve_cycles(unsigned long long* out8) {
+    GANQ_HIP_CHECK(hipDeviceSynchronize());
+    GANQ_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ganq::ss_dbg), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0};
+    GANQ_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ganq::ss_dbg), z, sizeof(z)));
+    return 0;
+}
+#endif
