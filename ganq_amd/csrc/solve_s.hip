@@ -60,13 +60,13 @@ struct PanelState {
 };
 
 // One column step.  JJ = column inside the panel; its owner is lane (JJ & 15) of each DPP row, register JJ >> 4.
+// dg = {L[j][j], RN(1 / L[j][j])} and lrow = L[j][j0 + c16 + 16k] (k = 0..3) were read from LDS one step earlier.
 template <int JJ>
-__device__ __forceinline__ void panel_step(PanelState& st, const float4 (*Ld)[16], const float2* Dg) {
+__device__ __forceinline__ void panel_step(PanelState& st, const float2 dg, const float4 lrow) {
     constexpr int KREG = JJ >> 4, OWN = JJ & 15;
     // r / L[j][j] as an exactly rounded quotient without the division sequence (Markstein): rinv = RN(1/L[j][j]) is
     // computed once per column with a true division; q0 = RN(r*rinv); e = fma(-q0, L, r) is exact; RN(q0 + e*rinv) is
     // the IEEE quotient (checked against the division by ganq_debug_div_check and, end to end, by the oracle tests)
-    const float2 dg = Dg[JJ];  // {L[j][j], RN(1 / L[j][j])}, uniform LDS read
     const float q0 = st.r[KREG] * dg.y;
     const float qe = fmaf(-q0, dg.x, st.r[KREG]);
     const float quo = fmaf(qe, dg.y, q0);
@@ -79,7 +79,6 @@ __device__ __forceinline__ void panel_step(PanelState& st, const float4 (*Ld)[16
     const uint32_t idx = row_min_u(cand);  // first minimum
     const uint32_t tb = row_or_u((st.c16 == idx) ? __builtin_bit_cast(uint32_t, st.tv) : 0u);
     const float err = wj - __builtin_bit_cast(float, tb);
-    const float4 lrow = Ld[JJ][st.c16];  // L[j][j0 + c16 + 16k], k = 0..3
     st.r[0] = fmaf(err, lrow.x, st.r[0]);
     st.r[1] = fmaf(err, lrow.y, st.r[1]);
     st.r[2] = fmaf(err, lrow.z, st.r[2]);
@@ -90,15 +89,25 @@ __device__ __forceinline__ void panel_step(PanelState& st, const float4 (*Ld)[16
     }
 }
 
+// steps run from the panel's last column down to its first; the LDS operands of step JJ-1 are fetched before the
+// dependent chain of step JJ starts (they depend on nothing the steps compute)
+template <bool FULL, int JJ>
+__device__ __forceinline__ void panel_from(PanelState& st, const float4 (*Ld)[16], const float2* Dg, int wd, float2 dg,
+                                           float4 lrow) {
+    float2 dg_n = dg;
+    float4 lrow_n = lrow;
+    if constexpr (JJ > 0) {
+        dg_n = Dg[JJ - 1];
+        lrow_n = Ld[JJ - 1][st.c16];
+    }
+    if (FULL || JJ < wd) panel_step<JJ>(st, dg, lrow);
+    if constexpr (JJ > 0) panel_from<FULL, JJ - 1>(st, Ld, Dg, wd, dg_n, lrow_n);
+}
+
 template <bool FULL, int... I>
 __device__ __forceinline__ void panel_all(PanelState& st, const float4 (*Ld)[16], const float2* Dg, int wd,
                                           std::integer_sequence<int, I...>) {
-    // steps run from the panel's last column down to its first
-    if constexpr (FULL) {
-        (panel_step<SB - 1 - I>(st, Ld, Dg), ...);
-    } else {
-        ((SB - 1 - I < wd ? panel_step<SB - 1 - I>(st, Ld, Dg) : (void)0), ...);
-    }
+    panel_from<FULL, SB - 1>(st, Ld, Dg, wd, Dg[SB - 1], Ld[SB - 1][st.c16]);
 }
 
 // Two roles per workgroup (8 waves, one of each role per SIMD):
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
         const int bG = nb - 1 - s;  // panel whose residual is produced in this step (none at s = nb)
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         float bpre[16];  // (G) L[(bG+1)*64 + 4g + kslot][colB], g = 0..15: the B operands of part 2
-        const unsigned long long t_step = SS_T();
+        [[maybe_unused]] const unsigned long long t_step = SS_T();
         if (!roleG) {
             // ---- (P) ---------------------------------------------------------------------------------------
             if (bP <= nb - 1) {
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                 }
                 const int gtop = (n >> 2) - 1;     // highest full group
                 const uint32_t laneB = (uint32_t)kslot * (uint32_t)ldl + (uint32_t)colB;
+                const uint32_t laneB4 = 4u * laneB;  // byte offset, < 2^32 (host check on ldl)
                 // One chain segment: groups ghi, ghi-1, .., glo (descending), A from LDS (columns >= cbase) or from the
                 // global transposed scratch.  Batches of SPF groups, operands loaded two batches ahead into three
                 // rotating register sets; every load is unconditional (indices clamped to the segment) so that the
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
 #pragma unroll
                         for (int i = 0; i < SPF; ++i) {
                             if constexpr (DBG == 1) bb[i] = 1.0f + (float)bi;
-                            else bb[i] = Bp[laneB];
+                            else bb[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bp) + laneB4);  // saddr + voffset
                             Bp += bstride;
                             if constexpr (DBG == 2) aa[i] = 1.0f + (float)bi;
                             else aa[i] = Ap[i * (4 * SR)];
@@ -344,6 +354,7 @@ extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const f
         return fail(-2, "ganq_solve_s: V=%d not supported (bits 2..4 are implemented; bits=8 is not)", V);
     if (m > INT32_MAX / 2 || n > INT32_MAX / 2) return fail(-1, "ganq_solve_s: shape too large");
     if (ldl < n) return fail(-1, "ganq_solve_s: ldl=%lld < n=%lld", (long long)ldl, (long long)n);
+    if (ldl > (1ll << 27)) return fail(-1, "ganq_solve_s: ldl=%lld too large", (long long)ldl);
     if (!W || !L || !T || !Q_out) return fail(-3, "ganq_solve_s: null pointer");
     const size_t need = ganq_solve_s_workspace_bytes(m, n, V);
     if (!workspace || workspace_bytes < need)
