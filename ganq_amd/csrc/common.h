@@ -60,6 +60,7 @@ enum KernelId : int {
     KID_LUT_GEMM,
     KID_PACK,
     KID_T_PREP,
+    KID_T_INCR,
     KID_COUNT
 };
 bool profile_enabled();

@@ -127,7 +127,7 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
         rc = ganq_solve_s(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, lo.solve_bytes, stream_);
         if (rc) return rc;
         // new codebook and, from the same A and b, the loss of (new codebook, these indices)  (ganq.py:589-591, :621-622)
-        rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, dists + k, stream);
+        rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, dists + k, k, stream);
         if (rc) return rc;
         std::swap(Tc, Tn);
         hipLaunchKernelGGL(best_select_kernel, dim3(1), dim3(1), 0, stream, dists + k, k, best, best_k, flag);

@@ -7,6 +7,8 @@ namespace ganq {
 struct TLayout {
     int64_t nq, ng;  // padded plane row pitch, number of 64-column mask groups
     size_t off_prep, off_planes, off_hdiag, off_bits, off_mpart, off_h64, off_wh64, off_whw, off_lossrows, total;
+    // incremental bucket sums (loop driver only): integer H, previous indices, per-row sums, change lists
+    size_t off_hint, off_qprev, off_mstate, off_chg, off_chgcnt;
 };
 
 TLayout t_layout(int64_t m, int64_t n, bool with_f64);
@@ -16,8 +18,11 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
               hipStream_t stream);
 
 // once per iteration.  WH32 != nullptr: b from the caller's fp32 W@H (stage API, no loss);
-// WH32 == nullptr: b from the fp64 product prepared by t_prepare, loss_out (device double) optional
+// WH32 == nullptr: b from the fp64 product prepared by t_prepare, loss_out (device double) optional.
+// iter < 0: stateless (full accumulation).  iter >= 0 (layout built with with_f64): the bucket sums are kept between
+// calls; iter == 0 accumulates them in full, later calls only move the H entries of the indices that changed
+// (exact: the sums are integers), falling back to the full accumulation on the device when too many changed.
 int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
-              float* T_out, float* A_out, float* b_out, double* loss_out, hipStream_t stream);
+              float* T_out, float* A_out, float* b_out, double* loss_out, int iter, hipStream_t stream);
 
 }  // namespace ganq

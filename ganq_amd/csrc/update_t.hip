@@ -61,7 +61,7 @@ __global__ void prep_scale_kernel(TPrep* prep) {
 // planes[p][v][u] (row pitch nq, zero padded), hdiag_int[u], optionally H64[v][u] = scale * integer
 __global__ __launch_bounds__(256) void hquant_kernel(const float* __restrict__ H, int n, int nq, const TPrep* __restrict__ prep,
                                                     int8_t* __restrict__ planes, int* __restrict__ hdiag_int,
-                                                    double* __restrict__ H64) {
+                                                    double* __restrict__ H64, int* __restrict__ Hint) {
     const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;  // 4 consecutive u of one row v
     const int64_t per_row = nq;
     if (i4 >= (int64_t)n * per_row) return;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void hquant_kernel(const float* __restrict__ H
             const double x = (double)H[(int64_t)v * n + u] * inv;
             xi = (int)__builtin_rint(fmin(fmax(x, -1073741824.0), 1073741824.0));
             if (H64) H64[(int64_t)v * n + u] = scale * (double)xi;
+            if (Hint) Hint[(int64_t)v * n + u] = xi;
             if (u == v) hdiag_int[u] = xi;
         }
         int r = xi;
@@ -93,8 +94,11 @@ __global__ __launch_bounds__(256) void hquant_kernel(const float* __restrict__ H
 }
 
 // bits[(row * ng + g) * 16 + a] : bit l set  <=>  Q[row][64 g + l] == a
+// `changed` (device, may be null): the full-accumulation kernels run only when *changed > thr
 __global__ __launch_bounds__(256) void code_masks_kernel(const uint8_t* __restrict__ Q, int m, int n, int ng,
-                                                        unsigned long long* __restrict__ bits) {
+                                                        unsigned long long* __restrict__ bits,
+                                                        const long long* __restrict__ changed, long long thr) {
+    if (changed && *changed <= thr) return;
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (int64_t)m * ng) return;
@@ -114,7 +118,9 @@ __global__ __launch_bounds__(256) void code_masks_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __restrict__ planes,
                                                               const unsigned long long* __restrict__ bits,
                                                               const uint8_t* __restrict__ Q, int m, int n, int nq, int ng,
-                                                              long long* __restrict__ Mpart, long long* __restrict__ stamps) {
+                                                              long long* __restrict__ Mpart, long long* __restrict__ stamps,
+                                                              const long long* __restrict__ changed, long long thr) {
+    if (changed && *changed <= thr) return;
     extern __shared__ __align__(16) char smem[];
     long long st_pro = 0, st_loop = 0, st_flush = 0, st_t0 = 0;
     char* Bbuf = smem;                                                        // 2 x BTILE
@@ -290,13 +296,197 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Incremental bucket sums.  F_i[a][b] = sum_{u != v} [Q_iu = a][Q_iv = b] Hint[u][v] (= M + M^T of the full
+// accumulation) is an integer, so moving the entries of the columns whose index changed reproduces exactly what a
+// full accumulation over the new indices gives.
+
+// Mstate[row] = F = M + M^T with M = sum_p Mpart[p][row]; Qprev = Q   (after a full accumulation)
+__global__ __launch_bounds__(256) void m_reduce_kernel(const long long* __restrict__ Mpart, int m, long long* __restrict__ Mstate,
+                                                      const uint8_t* __restrict__ Q, uint8_t* __restrict__ Qprev, int64_t qbytes,
+                                                      const long long* __restrict__ changed, long long thr) {
+    if (changed && *changed <= thr) return;
+    const int64_t total = (int64_t)m * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t it = (i & ~255ll) | ((i & 15) << 4) | ((i >> 4) & 15);  // the transposed cell of the same row
+        long long s = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s += Mpart[(int64_t)p * total + i] + Mpart[(int64_t)p * total + it];
+        Mstate[i] = s;
+    }
+    const int64_t q16 = qbytes / 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < q16; i += (int64_t)gridDim.x * 256)
+        reinterpret_cast<uint4*>(Qprev)[i] = reinterpret_cast<const uint4*>(Q)[i];
+    for (int64_t i = q16 * 16 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < qbytes; i += (int64_t)gridDim.x * 256) Qprev[i] = Q[i];
+}
+
+// one wave per row: columns whose index differs from the previous iteration -> chg[row][0..cnt), chgcnt[row]; *changed += cnt
+__global__ __launch_bounds__(256) void q_diff_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ Qprev, int m, int n,
+                                                    uint16_t* __restrict__ chg, int* __restrict__ chgcnt,
+                                                    long long* __restrict__ changed) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const uint8_t* q = Q + (int64_t)row * n;
+    const uint8_t* qp = Qprev + (int64_t)row * n;
+    uint16_t* out = chg + (int64_t)row * n;
+    int cnt = 0;
+    int xdone = 0;
+    if ((n & 15) == 0) {  // rows are 16-byte aligned: 1 KB of each row per step, 4 steps in flight
+        const int n16 = n >> 4;
+        for (int i0 = 0; i0 < n16; i0 += 64 * 4) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + 64 * k + lane;
+                a[k] = i < n16 ? reinterpret_cast<const uint4*>(q)[i] : make_uint4(0, 0, 0, 0);
+                b[k] = i < n16 ? reinterpret_cast<const uint4*>(qp)[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + 64 * k + lane;
+                const uint32_t dw[4] = {a[k].x ^ b[k].x, a[k].y ^ b[k].y, a[k].z ^ b[k].z, a[k].w ^ b[k].w};
+                if (__ballot((dw[0] | dw[1] | dw[2] | dw[3]) != 0) == 0) continue;  // uniform
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int by = 0; by < 4; ++by) {
+                        const bool d = ((dw[w] >> (8 * by)) & 0xffu) != 0;
+                        const unsigned long long mk = __ballot(d);
+                        if (d) out[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)(16 * i + 4 * w + by);
+                        cnt += __popcll(mk);
+                    }
+            }
+        }
+        xdone = n;
+    }
+    for (int x0 = xdone; x0 < n; x0 += 64) {
+        const int x = x0 + lane;
+        const bool d = x < n && q[x] != qp[x];
+        const unsigned long long mk = __ballot(d);
+        if (d) out[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)x;
+        cnt += __popcll(mk);
+    }
+    if (lane == 0) {
+        chgcnt[row] = cnt;
+        if (cnt) atomicAdd(reinterpret_cast<unsigned long long*>(changed), (unsigned long long)cnt);
+    }
+}
+
+// one wave per row, the changed columns one after the other against the row's CURRENT indices (LDS copy).
+// Column c goes a_old -> a_new: with S[b] = sum_{x != c, code[x] = b} Hint[c][x],
+//   F[a_old][b] -= S[b], F[b][a_old] -= S[b], F[a_new][b] += S[b], F[b][a_new] += S[b]   for every b.
+// S is a 16-bucket histogram of one row of Hint: lane-private buckets in LDS ([bucket][lane]: no conflicts), then a
+// transposed read sums each bucket over the lanes.
+constexpr int MU_WAVES = 4;
+__global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __restrict__ Hint, const uint8_t* __restrict__ Q,
+                                                                uint8_t* __restrict__ Qprev, int m, int n,
+                                                                const uint16_t* __restrict__ chg, const int* __restrict__ chgcnt,
+                                                                long long* __restrict__ Mstate,
+                                                                const long long* __restrict__ changed, long long thr) {
+    if (*changed > thr) return;  // the full accumulation runs instead
+    extern __shared__ __align__(16) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * MU_WAVES + wv;
+    if (row >= m) return;
+    const int cnt = chgcnt[row];
+    if (cnt == 0) return;
+    long long* Frow = reinterpret_cast<long long*>(smem) + wv * 256;                                  // [16][16]
+    long long* priv = reinterpret_cast<long long*>(smem) + MU_WAVES * 256 + wv * (16 * 64);           // [16][64]
+    uint8_t* codes = reinterpret_cast<uint8_t*>(smem) + (size_t)MU_WAVES * (256 + 16 * 64) * sizeof(long long) +
+                     (size_t)wv * align_up((size_t)n, 16);
+    long long* Fg = Mstate + (int64_t)row * 256;
+    uint8_t* qp = Qprev + (int64_t)row * n;
+    const uint8_t* qn = Q + (int64_t)row * n;
+    for (int i = lane; i < 256; i += 64) Frow[i] = Fg[i];
+    for (int x = lane; x < n; x += 64) codes[x] = min((int)qp[x], 15);
+    wave_sync();
+    const uint16_t* list = chg + (int64_t)row * n;
+    // The work is a stream of (changed column, 4096-column chunk of its Hint row) items.  One wave per row makes every
+    // row a chain of dependent L2 / HBM round trips, so the next item's 16 KB are always in flight (16 x 16 B per
+    // lane) while the current one is bucketed.
+    constexpr int CH = 16;                       // int4 loads per lane and chunk: 64 * 16 * 4 = 4096 columns
+    const bool vec = (n & 3) == 0;               // rows of Hint are 16-byte aligned
+    const int nchunk = (n + 64 * CH * 4 - 1) / (64 * CH * 4);
+    const int nitems = cnt * nchunk;
+    auto load_item = [&](int it, int4 (&buf)[CH]) {
+        const int e = it / nchunk, k = it - e * nchunk;
+        const int* hrow = Hint + (int64_t)list[e] * n;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int x = 4 * (64 * (CH * k + j) + lane);
+            int4 v = make_int4(0, 0, 0, 0);
+            if (vec) {
+                if (x < n) v = *reinterpret_cast<const int4*>(hrow + x);
+            } else {
+                if (x < n) v.x = hrow[x];
+                if (x + 1 < n) v.y = hrow[x + 1];
+                if (x + 2 < n) v.z = hrow[x + 2];
+                if (x + 3 < n) v.w = hrow[x + 3];
+            }
+            buf[j] = v;
+        }
+    };
+    auto bucket_item = [&](int it, const int4 (&buf)[CH]) {
+        const int e = it / nchunk, k = it - e * nchunk;
+        const int c = list[e];
+        if (k == 0) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) priv[b * 64 + lane] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int x = 4 * (64 * (CH * k + j) + lane);
+            const int hv[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (x + t < n && x + t != c)  // private slot; a fire-and-forget LDS add keeps the 64 updates from serialising
+                    __hip_atomic_fetch_add(&priv[(int)codes[x + t] * 64 + lane], (long long)hv[t], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        if (k != nchunk - 1) return;
+        // column finished: bucket b = lane & 15 summed over lanes 16*(lane>>4) .. +15, then over the four quarters
+        wave_sync();
+        const int a_old = codes[c], a_new = min((int)qn[c], 15);
+        long long sb = 0;
+        {
+            const long long* pb = priv + (lane & 15) * 64 + 16 * (lane >> 4);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) sb += pb[t];
+        }
+        sb += __shfl_xor(sb, 16);
+        sb += __shfl_xor(sb, 32);
+        if (lane < 16) {  // lane = b; no two lanes touch the same cell
+            Frow[a_old * 16 + lane] -= sb;
+            Frow[lane * 16 + a_old] -= sb;
+            Frow[a_new * 16 + lane] += sb;
+            Frow[lane * 16 + a_new] += sb;
+        }
+        if (lane == 0) {
+            codes[c] = (uint8_t)a_new;
+            qp[c] = qn[c];
+        }
+        wave_sync();
+    };
+    int4 buf0[CH], buf1[CH];
+    load_item(0, buf0);
+    for (int it = 0; it < nitems; it += 2) {
+        if (it + 1 < nitems) load_item(it + 1, buf1);
+        bucket_item(it, buf0);
+        if (it + 1 >= nitems) break;
+        if (it + 2 < nitems) load_item(it + 2, buf0);
+        bucket_item(it + 1, buf1);
+    }
+    for (int i = lane; i < 256; i += 64) Fg[i] = Frow[i];
+}
+
 template <typename WHT>
 __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict__ Mpart, const TPrep* __restrict__ prep,
                                                      const int* __restrict__ hdiag_int, const WHT* __restrict__ WH,
                                                      const double* __restrict__ wHw, const uint8_t* __restrict__ Q, int m,
                                                      int n, int V, double rcond, float* __restrict__ T_out,
                                                      float* __restrict__ A_out, float* __restrict__ b_out,
-                                                     double* __restrict__ loss_rows) {
+                                                     double* __restrict__ loss_rows, int nparts) {
     __shared__ double As[4][16][JS];
     __shared__ double Es[4][16][JS];
     __shared__ double A0[4][16][JS];       // unrounded A (for the loss), also scratch for the bucket sums
@@ -343,7 +533,8 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     long long col[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) col[a] = 0;
-    for (int p = 0; p < NP; ++p) {
+    const bool sym_in = nparts == 0;  // Mpart is already F = M + M^T (one part)
+    for (int p = 0; p < (sym_in ? 1 : nparts); ++p) {
         const long long* src = Mpart + ((int64_t)p * m + rowc) * 256;
 #pragma unroll
         for (int a = 0; a < 16; ++a) col[a] += src[a * 16 + l];
@@ -354,7 +545,7 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     double colA[16], colA0[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-        long long x = Di[rs][a][l] + Di[rs][l][a];
+        long long x = sym_in ? Di[rs][a][l] : Di[rs][a][l] + Di[rs][l][a];
         if (a == l) x += dsum;
         colA0[a] = scale * (double)x;
         colA[a] = (double)(float)colA0[a];  // the reference holds A and b in fp32
@@ -581,7 +772,13 @@ TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
     lo.off_bits = take((size_t)m * lo.ng * 16 * sizeof(unsigned long long));
     lo.off_mpart = take((size_t)NP * m * 256 * sizeof(long long));
     lo.off_h64 = lo.off_wh64 = lo.off_whw = lo.off_lossrows = 0;
+    lo.off_hint = lo.off_qprev = lo.off_mstate = lo.off_chg = lo.off_chgcnt = 0;
     if (with_f64) {
+        lo.off_hint = take((size_t)n * n * sizeof(int));
+        lo.off_qprev = take((size_t)m * n);
+        lo.off_mstate = take((size_t)m * 256 * sizeof(long long));
+        lo.off_chg = take((size_t)m * n * sizeof(uint16_t));
+        lo.off_chgcnt = take((size_t)m * sizeof(int) + 64);  // counts per row, then the 8-byte total
         lo.off_h64 = take((size_t)n * n * sizeof(double));
         lo.off_wh64 = take((size_t)m * n * sizeof(double));
         lo.off_whw = take((size_t)m * sizeof(double));
@@ -603,8 +800,9 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
     hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, stream, H, n * n, prep);
     hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(1), 0, stream, prep);
     const int64_t quads = n * lo.nq / 4;
+    int* Hint = with_f64 ? reinterpret_cast<int*>(ws + lo.off_hint) : nullptr;
     hipLaunchKernelGGL(hquant_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, H, (int)n, (int)lo.nq, prep,
-                       planes, hdiag, H64);
+                       planes, hdiag, H64, Hint);
     GANQ_LAUNCH_CHECK();
     if (with_f64) {
         double* WH64 = reinterpret_cast<double*>(ws + lo.off_wh64);
@@ -617,19 +815,46 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
     return 0;
 }
 
-// per iteration: masks -> integer accumulation -> per-row solve (+ loss rows)
+// per iteration: bucket sums (full: masks -> integer accumulation; or incremental) -> per-row solve (+ loss rows)
 int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
-              float* T_out, float* A_out, float* b_out, double* loss_out, hipStream_t stream) {
+              float* T_out, float* A_out, float* b_out, double* loss_out, int iter, hipStream_t stream) {
     TPrep* prep = reinterpret_cast<TPrep*>(ws + lo.off_prep);
     int8_t* planes = reinterpret_cast<int8_t*>(ws + lo.off_planes);
     int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws + lo.off_bits);
     long long* mpart = reinterpret_cast<long long*>(ws + lo.off_mpart);
+    const bool stateful = iter >= 0 && lo.off_hint != 0;
+    long long* mstate = stateful ? reinterpret_cast<long long*>(ws + lo.off_mstate) : nullptr;
+    uint8_t* qprev = stateful ? reinterpret_cast<uint8_t*>(ws + lo.off_qprev) : nullptr;
+    int* chgcnt = stateful ? reinterpret_cast<int*>(ws + lo.off_chgcnt) : nullptr;
+    long long* changed = stateful ? reinterpret_cast<long long*>(ws + lo.off_chgcnt + align_up((size_t)m * sizeof(int), 8)) : nullptr;
+    // more than 1/16 of all indices changed: the full accumulation is cheaper (decided on the device, no host sync)
+    const long long thr = (long long)((m * n) >> 4);
+    const long long* gate = nullptr;  // null: the full path runs unconditionally
+    if (stateful && iter > 0) {
+        ProfScope prof(KID_T_INCR, stream);
+        uint16_t* chg = reinterpret_cast<uint16_t*>(ws + lo.off_chg);
+        GANQ_HIP_CHECK(hipMemsetAsync(changed, 0, sizeof(long long), stream));
+        hipLaunchKernelGGL(q_diff_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, Q, qprev, (int)m, (int)n, chg, chgcnt,
+                           changed);
+        const size_t usmem = (size_t)MU_WAVES * ((256 + 16 * 64) * sizeof(long long) + align_up((size_t)n, 16));
+        static size_t attr_usmem = 0;
+        if (usmem > 64 * 1024 && usmem > attr_usmem) {
+            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(m_update_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)usmem));
+            attr_usmem = usmem;
+        }
+        hipLaunchKernelGGL(m_update_kernel, dim3((unsigned)((m + MU_WAVES - 1) / MU_WAVES)), dim3(MU_WAVES * 64), usmem, stream,
+                           reinterpret_cast<const int*>(ws + lo.off_hint), Q, qprev, (int)m, (int)n, chg, chgcnt, mstate, changed,
+                           thr);
+        GANQ_LAUNCH_CHECK();
+        gate = changed;
+    }
     {
         ProfScope prof(KID_SORT_CODES, stream);
         const int64_t items = m * lo.ng;
         hipLaunchKernelGGL(code_masks_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, Q, (int)m, (int)n,
-                           (int)lo.ng, bits);
+                           (int)lo.ng, bits, gate, thr);
     }
     GANQ_LAUNCH_CHECK();
     static bool attr_set = false;
@@ -646,7 +871,7 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         long long* stamps = nullptr;
         if (dbg) (void)hipMalloc(&stamps, 64);
         hipLaunchKernelGGL(onehot_accum_kernel, dim3((unsigned)(nrg * NP)), dim3(TW * 64), smem, stream, planes, bits, Q, (int)m,
-                           (int)n, (int)lo.nq, (int)lo.ng, mpart, stamps);
+                           (int)n, (int)lo.nq, (int)lo.ng, mpart, stamps, gate, thr);
         if (stamps) {
             long long h[3];
             (void)hipStreamSynchronize(stream);
@@ -654,21 +879,25 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
             (void)hipFree(stamps);
             fprintf(stderr, "[onehot_accum stamps] wg0 wave0: prologue %lld, tile loop %lld, flush %lld cycles\n", h[0], h[1], h[2]);
         }
+        if (stateful)
+            hipLaunchKernelGGL(m_reduce_kernel, dim3(1024), dim3(256), 0, stream, mpart, (int)m, mstate, Q, qprev, m * n, gate, thr);
     }
     GANQ_LAUNCH_CHECK();
     {
         ProfScope prof(KID_T_SOLVE, stream);
         const dim3 grid((unsigned)((m + 3) / 4));
+        const long long* msrc = stateful ? mstate : mpart;
+        const int nparts = stateful ? 0 : NP;  // 0: one part that is already symmetric
         if (WH32) {
-            hipLaunchKernelGGL(t_solve_kernel<float>, grid, dim3(64), 0, stream, mpart, prep, hdiag, WH32,
+            hipLaunchKernelGGL(t_solve_kernel<float>, grid, dim3(64), 0, stream, msrc, prep, hdiag, WH32,
                                static_cast<const double*>(nullptr), Q, (int)m, (int)n, V, rcond, T_out, A_out, b_out,
-                               static_cast<double*>(nullptr));
+                               static_cast<double*>(nullptr), nparts);
         } else {
             const double* WH64 = reinterpret_cast<const double*>(ws + lo.off_wh64);
             const double* wHw = reinterpret_cast<const double*>(ws + lo.off_whw);
             double* loss_rows = reinterpret_cast<double*>(ws + lo.off_lossrows);
-            hipLaunchKernelGGL(t_solve_kernel<double>, grid, dim3(64), 0, stream, mpart, prep, hdiag, WH64, wHw, Q, (int)m,
-                               (int)n, V, rcond, T_out, A_out, b_out, loss_out ? loss_rows : nullptr);
+            hipLaunchKernelGGL(t_solve_kernel<double>, grid, dim3(64), 0, stream, msrc, prep, hdiag, WH64, wHw, Q, (int)m,
+                               (int)n, V, rcond, T_out, A_out, b_out, loss_out ? loss_rows : nullptr, nparts);
             if (loss_out) hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, loss_rows, (int)m, loss_out);
         }
     }
@@ -702,5 +931,5 @@ extern "C" int ganq_update_t(const float* WH, const float* H, const uint8_t* Q, 
     char* ws = static_cast<char*>(workspace);
     int rc = t_prepare(nullptr, H, m, n, lo, ws, false, stream);
     if (rc) return rc;
-    return t_iterate(Q, m, n, V, rcond, lo, ws, WH, T_out, A_out, b_out, nullptr, stream);
+    return t_iterate(Q, m, n, V, rcond, lo, ws, WH, T_out, A_out, b_out, nullptr, -1, stream);
 }
