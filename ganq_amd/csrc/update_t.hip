@@ -373,12 +373,14 @@ __global__ __launch_bounds__(256) void q_diff_kernel(const uint8_t* __restrict__
     }
 }
 
-// one wave per row, the changed columns one after the other against the row's CURRENT indices (LDS copy).
-// Column c goes a_old -> a_new: with S[b] = sum_{x != c, code[x] = b} Hint[c][x],
-//   F[a_old][b] -= S[b], F[b][a_old] -= S[b], F[a_new][b] += S[b], F[b][a_new] += S[b]   for every b.
-// S is a 16-bucket histogram of one row of Hint: lane-private buckets in LDS ([bucket][lane]: no conflicts), then a
-// transposed read sums each bucket over the lanes.
-constexpr int MU_WAVES = 4;
+// One workgroup per row, its waves share out the changed columns.  Column c = list[e] goes a_old -> a_new.  Taking the
+// changes in list order, the codes seen by step e are the new ones for list[e' < e] and the old ones elsewhere, so with
+//   S_e[b] = sum_{x != c, old[x] = b} Hint[c][x]  +  sum_{e' < e} Hint[c][list[e']] * ([new[e'] = b] - [old[e'] = b])
+// the step is   F[a_old][b] -= S_e[b], F[b][a_old] -= S_e[b], F[a_new][b] += S_e[b], F[b][a_new] += S_e[b]  for every b.
+// No S_e depends on F or on another S, so the steps run in parallel and add into the row's F with LDS atomics.
+// S_e is a 16-bucket histogram of one row of Hint: lane-private buckets in LDS ([bucket][lane]: no conflicts), then
+// a transposed read sums each bucket over the lanes; the second sum is just 2 more entries per earlier change.
+constexpr int MU_WAVES = 8;
 __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __restrict__ Hint, const uint8_t* __restrict__ Q,
                                                                 uint8_t* __restrict__ Qprev, int m, int n,
                                                                 const uint16_t* __restrict__ chg, const int* __restrict__ chgcnt,
@@ -386,32 +388,35 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
                                                                 const long long* __restrict__ changed, long long thr) {
     if (*changed > thr) return;  // the full accumulation runs instead
     extern __shared__ __align__(16) char smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int row = blockIdx.x * MU_WAVES + wv;
-    if (row >= m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = blockIdx.x;
     const int cnt = chgcnt[row];
     if (cnt == 0) return;
-    long long* Frow = reinterpret_cast<long long*>(smem) + wv * 256;                                  // [16][16]
-    long long* priv = reinterpret_cast<long long*>(smem) + MU_WAVES * 256 + wv * (16 * 64);           // [16][64]
-    uint8_t* codes = reinterpret_cast<uint8_t*>(smem) + (size_t)MU_WAVES * (256 + 16 * 64) * sizeof(long long) +
-                     (size_t)wv * align_up((size_t)n, 16);
+    long long* Frow = reinterpret_cast<long long*>(smem);                                   // [16][16]
+    long long* priv = reinterpret_cast<long long*>(smem) + 256 + wv * (16 * 64);            // [16][64] per wave
+    uint8_t* codes = reinterpret_cast<uint8_t*>(smem) + (size_t)(256 + MU_WAVES * 16 * 64) * sizeof(long long);  // old
     long long* Fg = Mstate + (int64_t)row * 256;
     uint8_t* qp = Qprev + (int64_t)row * n;
     const uint8_t* qn = Q + (int64_t)row * n;
-    for (int i = lane; i < 256; i += 64) Frow[i] = Fg[i];
-    for (int x = lane; x < n; x += 64) codes[x] = min((int)qp[x], 15);
-    wave_sync();
+    for (int i = tid; i < 256; i += MU_WAVES * 64) Frow[i] = Fg[i];
+    for (int x = tid; x < n; x += MU_WAVES * 64) codes[x] = min((int)qp[x], 15);
+    __syncthreads();
     const uint16_t* list = chg + (int64_t)row * n;
-    // The work is a stream of (changed column, 4096-column chunk of its Hint row) items.  One wave per row makes every
-    // row a chain of dependent L2 / HBM round trips, so the next item's 16 KB are always in flight (16 x 16 B per
-    // lane) while the current one is bucketed.
+    // The work of a wave is a stream of (its changed column, 4096-column chunk of that Hint row) items.  Every item is
+    // a dependent L2 / HBM round trip, so the next item's 16 KB are always in flight (16 x 16 B per lane) while the
+    // current one is bucketed.
     constexpr int CH = 16;                       // int4 loads per lane and chunk: 64 * 16 * 4 = 4096 columns
     const bool vec = (n & 3) == 0;               // rows of Hint are 16-byte aligned
     const int nchunk = (n + 64 * CH * 4 - 1) / (64 * CH * 4);
-    const int nitems = cnt * nchunk;
-    auto load_item = [&](int it, int4 (&buf)[CH]) {
-        const int e = it / nchunk, k = it - e * nchunk;
+    const int mycols = (cnt - wv + MU_WAVES - 1) / MU_WAVES;  // e = wv, wv + MU_WAVES, ..
+    const int nitems = mycols * nchunk;
+    // this lane's earlier-change partner e' = lane (the first 64 changes; later ones take the slow loop below)
+    const int pc = lane < cnt ? list[lane] : 0;
+    const int p_old = lane < cnt ? codes[pc] : 0, p_new = lane < cnt ? min((int)qn[pc], 15) : 0;
+    auto load_item = [&](int it, int4 (&buf)[CH], int& corr) {
+        const int e = wv + (it / nchunk) * MU_WAVES, k = it % nchunk;
         const int* hrow = Hint + (int64_t)list[e] * n;
+        corr = (k == 0 && lane < e) ? hrow[pc] : 0;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int x = 4 * (64 * (CH * k + j) + lane);
@@ -427,12 +432,25 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
             buf[j] = v;
         }
     };
-    auto bucket_item = [&](int it, const int4 (&buf)[CH]) {
-        const int e = it / nchunk, k = it - e * nchunk;
+    auto lds_add = [&](long long* p, long long v) {  // fire-and-forget LDS add
+        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto bucket_item = [&](int it, const int4 (&buf)[CH], int corr) {
+        const int e = wv + (it / nchunk) * MU_WAVES, k = it % nchunk;
         const int c = list[e];
         if (k == 0) {
 #pragma unroll
             for (int b = 0; b < 16; ++b) priv[b * 64 + lane] = 0;
+            if (lane < e && lane < 64) {  // partner e' = lane < e already carries its new code
+                lds_add(&priv[p_new * 64 + lane], (long long)corr);
+                lds_add(&priv[p_old * 64 + lane], -(long long)corr);
+            }
+            for (int e2 = 64 + lane; e2 < e; e2 += 64) {  // more than 64 changes in the row: rare
+                const int c2 = list[e2];
+                const long long v = Hint[(int64_t)c * n + c2];
+                lds_add(&priv[min((int)qn[c2], 15) * 64 + lane], v);
+                lds_add(&priv[(int)codes[c2] * 64 + lane], -v);
+            }
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
@@ -440,9 +458,7 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
             const int hv[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                if (x + t < n && x + t != c)  // private slot; a fire-and-forget LDS add keeps the 64 updates from serialising
-                    __hip_atomic_fetch_add(&priv[(int)codes[x + t] * 64 + lane], (long long)hv[t], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (x + t < n && x + t != c) lds_add(&priv[(int)codes[x + t] * 64 + lane], (long long)hv[t]);
         }
         if (k != nchunk - 1) return;
         // column finished: bucket b = lane & 15 summed over lanes 16*(lane>>4) .. +15, then over the four quarters
@@ -456,28 +472,29 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
         }
         sb += __shfl_xor(sb, 16);
         sb += __shfl_xor(sb, 32);
-        if (lane < 16) {  // lane = b; no two lanes touch the same cell
-            Frow[a_old * 16 + lane] -= sb;
-            Frow[lane * 16 + a_old] -= sb;
-            Frow[a_new * 16 + lane] += sb;
-            Frow[lane * 16 + a_new] += sb;
-        }
-        if (lane == 0) {
-            codes[c] = (uint8_t)a_new;
-            qp[c] = qn[c];
+        if (lane < 16) {  // lane = b
+            lds_add(&Frow[a_old * 16 + lane], -sb);
+            lds_add(&Frow[lane * 16 + a_old], -sb);
+            lds_add(&Frow[a_new * 16 + lane], sb);
+            lds_add(&Frow[lane * 16 + a_new], sb);
         }
         wave_sync();
     };
-    int4 buf0[CH], buf1[CH];
-    load_item(0, buf0);
-    for (int it = 0; it < nitems; it += 2) {
-        if (it + 1 < nitems) load_item(it + 1, buf1);
-        bucket_item(it, buf0);
-        if (it + 1 >= nitems) break;
-        if (it + 2 < nitems) load_item(it + 2, buf0);
-        bucket_item(it + 1, buf1);
+    if (nitems > 0) {
+        int4 buf0[CH], buf1[CH];
+        int corr0 = 0, corr1 = 0;
+        load_item(0, buf0, corr0);
+        for (int it = 0; it < nitems; it += 2) {
+            if (it + 1 < nitems) load_item(it + 1, buf1, corr1);
+            bucket_item(it, buf0, corr0);
+            if (it + 1 >= nitems) break;
+            if (it + 2 < nitems) load_item(it + 2, buf0, corr0);
+            bucket_item(it + 1, buf1, corr1);
+        }
     }
-    for (int i = lane; i < 256; i += 64) Fg[i] = Frow[i];
+    __syncthreads();
+    for (int i = tid; i < 256; i += MU_WAVES * 64) Fg[i] = Frow[i];
+    for (int e = tid; e < cnt; e += MU_WAVES * 64) qp[list[e]] = qn[list[e]];
 }
 
 template <typename WHT>
@@ -823,13 +840,17 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
     int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws + lo.off_bits);
     long long* mpart = reinterpret_cast<long long*>(ws + lo.off_mpart);
-    const bool stateful = iter >= 0 && lo.off_hint != 0;
+    // test hooks: GANQ_T_FULL=1 -> stateless full accumulation every call; GANQ_T_INCR_THR=<count> -> device-side
+    // fallback threshold (changed indices per layer) instead of m*n/16
+    const char* env_full = getenv("GANQ_T_FULL");
+    const char* env_thr = getenv("GANQ_T_INCR_THR");
+    const bool stateful = iter >= 0 && lo.off_hint != 0 && !(env_full && env_full[0] == '1');
     long long* mstate = stateful ? reinterpret_cast<long long*>(ws + lo.off_mstate) : nullptr;
     uint8_t* qprev = stateful ? reinterpret_cast<uint8_t*>(ws + lo.off_qprev) : nullptr;
     int* chgcnt = stateful ? reinterpret_cast<int*>(ws + lo.off_chgcnt) : nullptr;
     long long* changed = stateful ? reinterpret_cast<long long*>(ws + lo.off_chgcnt + align_up((size_t)m * sizeof(int), 8)) : nullptr;
     // more than 1/16 of all indices changed: the full accumulation is cheaper (decided on the device, no host sync)
-    const long long thr = (long long)((m * n) >> 4);
+    const long long thr = env_thr ? atoll(env_thr) : (long long)((m * n) >> 4);
     const long long* gate = nullptr;  // null: the full path runs unconditionally
     if (stateful && iter > 0) {
         ProfScope prof(KID_T_INCR, stream);
@@ -837,14 +858,14 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         GANQ_HIP_CHECK(hipMemsetAsync(changed, 0, sizeof(long long), stream));
         hipLaunchKernelGGL(q_diff_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, Q, qprev, (int)m, (int)n, chg, chgcnt,
                            changed);
-        const size_t usmem = (size_t)MU_WAVES * ((256 + 16 * 64) * sizeof(long long) + align_up((size_t)n, 16));
+        const size_t usmem = (size_t)(256 + MU_WAVES * 16 * 64) * sizeof(long long) + align_up((size_t)n, 16);
         static size_t attr_usmem = 0;
         if (usmem > 64 * 1024 && usmem > attr_usmem) {
             GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(m_update_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)usmem));
             attr_usmem = usmem;
         }
-        hipLaunchKernelGGL(m_update_kernel, dim3((unsigned)((m + MU_WAVES - 1) / MU_WAVES)), dim3(MU_WAVES * 64), usmem, stream,
+        hipLaunchKernelGGL(m_update_kernel, dim3((unsigned)m), dim3(MU_WAVES * 64), usmem, stream,
                            reinterpret_cast<const int*>(ws + lo.off_hint), Q, qprev, (int)m, (int)n, chg, chgcnt, mstate, changed,
                            thr);
         GANQ_LAUNCH_CHECK();

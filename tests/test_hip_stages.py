@@ -226,6 +226,27 @@ def test_run_layer_vs_oracle(hip, oracle, m, n, V, K, seed):
     assert rel_fro(T.cpu().numpy(), To) < 1e-3 if frac > 0 else rel_fro(T.cpu().numpy(), To) < TOL_T
 
 
+@pytest.mark.parametrize("m,n,V,K,seed", [(96, 1024, 16, 6, 41), (40, 777, 8, 5, 42), (33, 250, 4, 4, 43), (64, 4112, 16, 3, 44)])
+def test_run_layer_incremental_equals_full(hip, m, n, V, K, seed, monkeypatch):
+    # the loop keeps the integer bucket sums between iterations and only moves the entries of changed indices;
+    # that must be bit-identical to re-accumulating everything, also through the device-side fallback
+    W, H, L, T0 = synth(m, n, V, seed, corr=0.2)
+    args = (dev(W), dev(H), dev(L), dev(T0), K)
+    ref = None
+    for env in ({"GANQ_T_FULL": "1"}, {}, {"GANQ_T_INCR_THR": "0"}, {"GANQ_T_INCR_THR": str(m * n // 400)}):
+        for k in ("GANQ_T_FULL", "GANQ_T_INCR_THR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        T, Q, d, bk = hip.run_layer(*args, alias_q=False)
+        out = (T.clone(), Q.clone(), d.clone(), int(bk))
+        if ref is None:
+            ref = out
+        else:
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2]), env
+            assert out[3] == ref[3]
+
+
 def test_reciprocal_quotient_equals_ieee_division(hip):
     # the S-solve replaces r / L[j][j] by a reciprocal-based sequence that must round like the division
     bad, first = hip.debug_div_check(1 << 30, seed=7)
