@@ -125,6 +125,9 @@ __device__ unsigned long long ss_dbg[8];
 #define SS_T() 0ull
 #define SS_ADD(slot, t0, who) do {} while (0)
 #endif
+// keeps a batch of loads where it was written: the memory clobber stops IR-level load motion across stage boundaries,
+// the sched_barrier stops the machine scheduler
+#define GANQ_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 template <bool KASC, int DBG = 0>
 __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ W, const float* __restrict__ L,
                                                       int64_t ldl, const float* __restrict__ T, int m, int n, int V,
@@ -182,7 +185,9 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
 #pragma unroll
                     for (int k = 0; k < 4; ++k) wnext[k] = W[(int64_t)prow * n + j0 - SB + c16 + 16 * k];  // full panel
                 }
-                if (wd == SB) {
+                if constexpr (DBG == 5) {
+                    // developer experiment: no panel steps at all (G role alone)
+                } else if (wd == SB) {
                     panel_all<true>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
                 } else {
                     panel_all<false>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
@@ -241,6 +246,10 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                 const int gtop = (n >> 2) - 1;     // highest full group
                 const uint32_t laneB = (uint32_t)kslot * (uint32_t)ldl + (uint32_t)colB;
                 const uint32_t laneB4 = 4u * laneB;  // byte offset, < 2^32 (host check on ldl)
+                const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L), 0, 0x7fffffff, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0x7fffffff, 0x00020000);
+                // zero records: every load through it is out of range and returns 0
+                const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L), 0, 0, 0x00020000);
                 // One chain segment: groups ghi, ghi-1, .., glo (descending), A from LDS (columns >= cbase) or from the
                 // global transposed scratch.  Batches of SPF groups, operands loaded two batches ahead into three
                 // rotating register sets; every load is unconditional (indices clamped to the segment) so that the
@@ -251,19 +260,29 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                     if (total <= 0) return;
                     const int nbat = total / SPF;
                     const float* __restrict__ Al = ErrL + (int64_t)laneA - (int64_t)cbase * SR;
-                    const int64_t bstride = 4 * ldl;  // floats between the B rows of consecutive groups
+                    // buffer loads: (resource, per-lane byte offset in a VGPR, per-group byte offset in an SGPR) -- one
+                    // scalar add and one VMEM instruction per operand, no per-lane 64-bit address arithmetic
+                    const uint32_t bstride_b = (uint32_t)(16 * ldl);  // bytes between the B rows of consecutive groups
+                    // Batches past the end (the loop below always runs whole rounds of three) multiply Err by zeros: their B
+                    // operand comes through rsrcZ (zero records: out-of-range buffer loads return 0), which leaves the accumulator as it is.
                     auto ld = [&](int bi, float (&aa)[SPF], float (&bb)[SPF]) {
                         // lowest group of the batch; everything else is a compile-time multiple of a stride above it
+                        const bool real = bi < nbat;
                         const int glow = ghi - min(bi, nbat - 1) * SPF - (SPF - 1);
-                        const float* __restrict__ Bp = L + (int64_t)glow * bstride;          // uniform
-                        const float* __restrict__ Ap = ALDS ? Al + glow * (4 * SR) : errt + (int64_t)glow * (4 * SR) + laneA;
+                        uint32_t sB = real ? (uint32_t)glow * bstride_b : 0u;
+                        const uint32_t stepB = real ? bstride_b : 0u;
+                        const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
+                        uint32_t sA = (uint32_t)glow * (uint32_t)(4 * SR * sizeof(float));
+                        const float* __restrict__ Ap = Al + glow * (4 * SR);
 #pragma unroll
                         for (int i = 0; i < SPF; ++i) {
                             if constexpr (DBG == 1) bb[i] = 1.0f + (float)bi;
-                            else bb[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bp) + laneB4);  // saddr + voffset
-                            Bp += bstride;
+                            else bb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)laneB4, (int)sB, 0));
+                            sB += stepB;
                             if constexpr (DBG == 2) aa[i] = 1.0f + (float)bi;
-                            else aa[i] = Ap[i * (4 * SR)];
+                            else if constexpr (ALDS) aa[i] = Ap[i * (4 * SR)];
+                            else aa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcE, (int)(4 * laneA), (int)sA, 0));
+                            sA += 4 * SR * sizeof(float);
                         }
                     };
                     auto mm = [&](const float (&aa)[SPF], const float (&bb)[SPF]) {
@@ -275,27 +294,36 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                     };
                     if (nbat > 0) {
                         float a0[SPF], b0[SPF], a1[SPF], b1[SPF], a2[SPF], b2[SPF];
-                        // sched_barrier: the scheduler must not sink a batch of loads towards its use two batches later
                         ld(0, a0, b0);
                         ld(1, a1, b1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        int bi = 0;
-                        while (true) {
+                        GANQ_PIN();
+                        // One stage = the loads of batch k+2 and the 16 MFMAs of batch k, interleaved one load (two when A
+                        // also comes from memory) per MFMA: a lone wave issues a VMEM instruction every ~16 cycles and a
+                        // dependent MFMA every ~40, so loads issued as a block in front of the MFMAs leave the matrix
+                        // pipe idle for a third of the stage.
+                        auto stage_sched = [&]() {
+#pragma unroll
+                            for (int i = 0; i < SPF / 2; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x020, ALDS ? 1 : 2, 0);        // VMEM read
+                                if (ALDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // DS read
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x020, ALDS ? 1 : 2, 0);
+                            }
+                        };
+                        for (int bi = 0; bi < nbat; bi += 3) {  // whole rounds, no exits inside: a plain counted loop
                             ld(bi + 2, a2, b2);
-                            __builtin_amdgcn_sched_barrier(0);
                             mm(a0, b0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (++bi == nbat) break;
-                            ld(bi + 2, a0, b0);
-                            __builtin_amdgcn_sched_barrier(0);
+                            stage_sched();
+                            GANQ_PIN();
+                            ld(bi + 3, a0, b0);
                             mm(a1, b1);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (++bi == nbat) break;
-                            ld(bi + 2, a1, b1);
-                            __builtin_amdgcn_sched_barrier(0);
+                            stage_sched();
+                            GANQ_PIN();
+                            ld(bi + 4, a1, b1);
                             mm(a2, b2);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (++bi == nbat) break;
+                            stage_sched();
+                            GANQ_PIN();
                         }
                     }
                     for (int g = ghi - nbat * SPF; g >= glo; --g) {  // fewer than SPF groups left (ragged n only)
@@ -354,7 +382,7 @@ extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const f
         return fail(-2, "ganq_solve_s: V=%d not supported (bits 2..4 are implemented; bits=8 is not)", V);
     if (m > INT32_MAX / 2 || n > INT32_MAX / 2) return fail(-1, "ganq_solve_s: shape too large");
     if (ldl < n) return fail(-1, "ganq_solve_s: ldl=%lld < n=%lld", (long long)ldl, (long long)n);
-    if (ldl > (1ll << 27)) return fail(-1, "ganq_solve_s: ldl=%lld too large", (long long)ldl);
+    if (ldl * n > (1ll << 29)) return fail(-1, "ganq_solve_s: L of %lld x %lld floats exceeds the 2 GiB buffer window", (long long)n, (long long)ldl);
     if (!W || !L || !T || !Q_out) return fail(-3, "ganq_solve_s: null pointer");
     const size_t need = ganq_solve_s_workspace_bytes(m, n, V);
     if (!workspace || workspace_bytes < need)
@@ -383,9 +411,11 @@ extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const f
         GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         if (d == 1) GANQ_DBG_LAUNCH(1);
         else if (d == 2) GANQ_DBG_LAUNCH(2);
         else if (d == 3) GANQ_DBG_LAUNCH(3);
+        else if (d == 5) GANQ_DBG_LAUNCH(5);
         else GANQ_DBG_LAUNCH(0);
         GANQ_LAUNCH_CHECK();
         return 0;

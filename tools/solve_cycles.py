@@ -11,8 +11,8 @@ _lib.selftest()
 out = (ctypes.c_ulonglong * 8)()
 lib = _lib.lib()
 wgs = m // 16
-names = {0: "as shipped", 1: "no B loads", 2: "no A reads", 3: "no MFMA (one VALU fma per group)"}
-for mode in (0, 1, 2, 3):
+names = {0: "as shipped", 1: "no B loads", 2: "no A reads", 3: "no MFMA (one VALU fma per group)", 5: "no panel steps (G alone)"}
+for mode in (0, 1, 2, 3, 5):
     os.environ["GANQ_SOLVE_DBG"] = str(mode)
     _lib.solve_s(W, L, T0)
     lib.ganq_debug_solve_cycles(out)
