@@ -717,53 +717,80 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const double* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 // fp64 GEMM C[M,N] = A[M,K] (fp32, widened on load) @ B[K,N] (fp64) on v_mfma_f64_16x16x4_f64; used once per layer
 // for W @ H_fixed.  64x64 tile, 4 waves x (2x2 tiles of 16x16), K slabs of 16 through LDS.
-constexpr int DM = 64, DN = 64, DK = 16;
+// C[M,N] (fp64) = A[M,K] (fp32, widened) @ B[K,N] (fp64) on v_mfma_f64_16x16x4_f64.
+// 128x128 tile per workgroup, 4 waves of 64x64 (4x4 MFMA tiles: 8 LDS reads per 16 MFMAs), 16-deep k slabs double
+// buffered in LDS, the next slab's global loads in flight during the current slab's MFMAs.
+constexpr int DM = 128, DN = 128, DK = 16;
+constexpr int DPAD = 4;  // row pitch DM + 4 doubles: the 16 lanes x 4 k-rows of an operand read hit distinct banks
 
 __global__ __launch_bounds__(256) void gemm_f64_kernel(const float* __restrict__ A, const double* __restrict__ B,
                                                       double* __restrict__ C, int M, int N, int K) {
-    __shared__ double As[DK][DM + 2];
-    __shared__ double Bs[DK][DN + 2];
+    __shared__ double As[2][DK][DM + DPAD];
+    __shared__ double Bs[2][DK][DN + DPAD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tiles_n = (N + DN - 1) / DN;
     const int bm = (blockIdx.x / tiles_n) * DM, bn = (blockIdx.x % tiles_n) * DN;
-    const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
-    f64x4 acc[2][2];
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    f64x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += DK) {
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+    // slab loads: A 128 rows x 16 k (fp32): thread -> row tid/2, 8 consecutive k; B 16 k x 128 cols (fp64): thread ->
+    // k tid/16, 8 consecutive columns
+    const int a_row = tid >> 1, a_k = (tid & 1) * 8;
+    const int b_k = tid >> 4, b_col = (tid & 15) * 8;
+    float ra[8];
+    double rb[8];
+    auto gload = [&](int k0) {
+        const int row = bm + a_row;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {  // A slab 64 x 16, B slab 16 x 64: 1024 elements each, 4 per thread
-            const int idx = e * 256 + tid;
-            const int ar = idx >> 4, ak = idx & 15;
-            const int row = bm + ar, k = k0 + ak;
-            As[ak][ar] = (row < M && k < K) ? (double)A[(int64_t)row * K + k] : 0.0;
-            const int bk = idx >> 6, bc = idx & 63;
-            const int kk = k0 + bk, col = bn + bc;
-            Bs[bk][bc] = (kk < K && col < N) ? B[(int64_t)kk * N + col] : 0.0;
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + a_k + e;
+            ra[e] = (row < M && k < K) ? A[(int64_t)row * K + k] : 0.0f;
         }
-        __syncthreads();
+        const int kk = k0 + b_k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = bn + b_col + e;
+            rb[e] = (kk < K && col < N) ? B[(int64_t)kk * N + col] : 0.0;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) As[buf][a_k + e][a_row] = (double)ra[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Bs[buf][b_k][b_col + e] = rb[e];
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    const int nslab = (K + DK - 1) / DK;
+    for (int sidx = 0; sidx < nslab; ++sidx) {
+        const int buf = sidx & 1;
+        if (sidx + 1 < nslab) gload((sidx + 1) * DK);
 #pragma unroll
         for (int kk = 0; kk < DK; kk += 4) {
             const int kq = kk + (lane >> 4);
-            double a[2], b[2];
+            double a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[kq][wm + 16 * i + (lane & 15)];
+            for (int i = 0; i < 4; ++i) a[i] = As[buf][kq][wm + 16 * i + (lane & 15)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[kq][wn + 16 * j + (lane & 15)];
+            for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kq][wn + 16 * j + (lane & 15)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (sidx + 1 < nslab) sstore(buf ^ 1);
         __syncthreads();
     }
     // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = bm + wm + 16 * i + (lane >> 4) + 4 * r;
