@@ -246,8 +246,8 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                 const int gtop = (n >> 2) - 1;     // highest full group
                 const uint32_t laneB = (uint32_t)kslot * (uint32_t)ldl + (uint32_t)colB;
                 const uint32_t laneB4 = 4u * laneB;  // byte offset, < 2^32 (host check on ldl)
-                const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L), 0, 0x7fffffff, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0x7fffffff, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L), 0, 0xffffffff, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);
                 // zero records: every load through it is out of range and returns 0
                 const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L), 0, 0, 0x00020000);
                 // One chain segment: groups ghi, ghi-1, .., glo (descending), A from LDS (columns >= cbase) or from the
@@ -382,7 +382,7 @@ extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const f
         return fail(-2, "ganq_solve_s: V=%d not supported (bits 2..4 are implemented; bits=8 is not)", V);
     if (m > INT32_MAX / 2 || n > INT32_MAX / 2) return fail(-1, "ganq_solve_s: shape too large");
     if (ldl < n) return fail(-1, "ganq_solve_s: ldl=%lld < n=%lld", (long long)ldl, (long long)n);
-    if (ldl * n > (1ll << 29)) return fail(-1, "ganq_solve_s: L of %lld x %lld floats exceeds the 2 GiB buffer window", (long long)n, (long long)ldl);
+    if (ldl * n >= (1ll << 30)) return fail(-1, "ganq_solve_s: L of %lld x %lld floats exceeds the 4 GiB buffer window", (long long)n, (long long)ldl);
     if (!W || !L || !T || !Q_out) return fail(-3, "ganq_solve_s: null pointer");
     const size_t need = ganq_solve_s_workspace_bytes(m, n, V);
     if (!workspace || workspace_bytes < need)

@@ -275,6 +275,9 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 
 // ---------------------------------------------------------------------------------------------------------------
 // 16 lanes per row, 4 rows per wave, 1 wave per workgroup.
+#ifndef GANQ_JACOBI_SWEEPS
+#define GANQ_JACOBI_SWEEPS 30
+#endif
 constexpr int JS = 17;  // padded leading dimension of the fp64 16x16 matrices in LDS
 
 __device__ __forceinline__ double row16_sum(double x) {
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
 
     // ---- round-robin Jacobi: 15 rounds of 8 disjoint rotations per sweep ----
     const int t = l >> 1;  // pair handled (redundantly) by lanes 2t, 2t+1
-    for (int sweep = 0; sweep < 30; ++sweep) {
+    for (int sweep = 0; sweep < GANQ_JACOBI_SWEEPS; ++sweep) {
         double off = 0.0, dg = 0.0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {

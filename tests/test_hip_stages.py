@@ -66,7 +66,9 @@ def test_solve_s_golden_bit_exact(hip, name):
 
 
 @pytest.mark.parametrize("m,n,V,seed", [(16, 64, 16, 1), (40, 200, 16, 2), (64, 320, 8, 3), (17, 100, 4, 4),
-                                        (256, 1024, 16, 5), (100, 1536, 8, 6)])
+                                        (256, 1024, 16, 5), (100, 1536, 8, 6),
+                                        # wider than the 1792 Err columns kept in LDS, ragged panel / k-group counts
+                                        (20, 1850, 16, 7), (33, 2001, 8, 8), (16, 1793, 16, 9), (18, 3000, 16, 10)])
 def test_solve_s_vs_oracle_bit_exact(hip, oracle, m, n, V, seed):
     W, H, L, T0 = synth(m, n, V, seed, corr=0.2 if seed % 2 else 0.0)
     Q, Err = hip.solve_s(dev(W), dev(L), dev(T0), want_err=True)
