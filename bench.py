@@ -63,7 +63,7 @@ def build_workload(args, dist, dev):
 
     class CaptureGANQ(GANQ):
         def _perform_quantization_loop(self, W, Hinv, blocksize, perm=None, invperm=None):
-            captured.update(W=W.clone(), Hinv_diag=torch.diagonal(Hinv).clone(), L=self.L, H=self.Xxt_damped)
+            captured.update(W=W.clone(), Hinv_diag=(Hinv if Hinv.dim() == 1 else torch.diagonal(Hinv)).clone(), L=self.L, H=self.Xxt_damped)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             T0 = self._initialize_codebook_kmeans(W, Hinv, self.qcfg.bits, W.device)

@@ -32,6 +32,8 @@ SIGNATURES = {
     "ganq_hip_selftest": (ctypes.c_int, [_c_vp]),
     "ganq_debug_div_check": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _c_vp, _c_vp, _c_vp]),
     "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp]),
+    "ganq_cholesky_workspace_bytes": (_c_sz, [_c_i64]),
+    "ganq_cholesky": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_kmeans_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
     "ganq_kmeans_init": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_solve_s_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
@@ -279,6 +281,26 @@ def hessian_accum(H, X, nsamples_before: int, batch: int):
     _check(lib().ganq_hessian_accum(H.data_ptr(), X.data_ptr(), code, rows, n, int(nsamples_before), int(batch),
                                     _stream()), "ganq_hessian_accum")
     return H
+
+
+def cholesky(H, check: bool = True):
+    """torch.linalg.cholesky(H) for a symmetric fp32 matrix on the GPU (lower factor, new tensor).  With check=True a
+    non-positive pivot raises torch.linalg.LinAlgError like torch does (one host sync); otherwise -> (L, info tensor)."""
+    H = _dev_f32(H, "H")
+    n = H.shape[0]
+    if H.shape != (n, n):
+        raise GanqHipError(f"cholesky: square matrix expected, got {tuple(H.shape)}")
+    L = H.clone()
+    info = torch.zeros((), dtype=torch.int32, device=H.device)
+    ws = _workspace(lib().ganq_cholesky_workspace_bytes(n), H.device)
+    _check(lib().ganq_cholesky(L.data_ptr(), n, L.stride(0) if n else 0, info.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+           "ganq_cholesky")
+    if not check:
+        return L, info
+    bad = int(info)
+    if bad:
+        raise torch.linalg.LinAlgError(f"ganq_cholesky: the input is not positive-definite (leading minor of order {bad})")
+    return L
 
 
 def kmeans_init(W, col_weight, V: int):

@@ -61,6 +61,7 @@ enum KernelId : int {
     KID_PACK,
     KID_T_PREP,
     KID_T_INCR,
+    KID_CHOLESKY,
     KID_COUNT
 };
 bool profile_enabled();

@@ -9,7 +9,7 @@ namespace ganq {
 static const char* const kNames[KID_COUNT] = {"solve_s_kernel", "gemm_f32_kernel", "code_masks_kernel",
                                               "onehot_accum_kernel", "t_solve_kernel", "err_kernel",
                                               "dot_reduce_kernels", "dequant_losses_kernel", "hessian_kernel",
-                                              "kmeans_kernels", "lut_gemv_kernel", "lut_gemm_kernel", "pack_kernels", "t_prepare_kernels", "t_incremental_kernels"};
+                                              "kmeans_kernels", "lut_gemv_kernel", "lut_gemm_kernel", "pack_kernels", "t_prepare_kernels", "t_incremental_kernels", "cholesky_kernels"};
 
 struct Span {
     int kid;

@@ -14,6 +14,11 @@ from .. import _lib
 from .gptq import GPTQ
 
 
+def _hinv_diag(Hinv):
+    """diag(Hinv) whether the prologue handed over the upper factor (reference op sequence) or only its diagonal."""
+    return Hinv if Hinv.dim() == 1 else torch.diagonal(Hinv)
+
+
 class GANQ(GPTQ):
     """Quantize following "GANQ: GPU-Adaptive Layer-Wise LUT-Based Non-Uniform Quantization" (arXiv 2501.12956)."""
 
@@ -24,11 +29,14 @@ class GANQ(GPTQ):
         self.ganq_codebook = None
         self.ganq_stats = {}
 
+    def _needs_only_hinv_diag(self) -> bool:
+        return True
+
     def _initialize_codebook_kmeans(self, W, Hinv, num_bits, device):
         """ganq.py:423-438: weighted 1-D k-means per row, column weight diag(Hinv)^-4 (computed in fp32 as the
         reference does before handing it to kmeans1d, which works in double)."""
         exp = 4
-        col_weight = (torch.diagonal(Hinv) ** (-exp)).double()
+        col_weight = (_hinv_diag(Hinv) ** (-exp)).double()
         return _lib.kmeans_init(W, col_weight, 2 ** num_bits)
 
     @torch.no_grad()
@@ -51,7 +59,7 @@ class GANQ(GPTQ):
         assert T0.shape == (W.shape[0], V)
         alias = bool(getattr(self.qcfg, "ganq_reference_q_alias", True))
         T, Q, dists, best_k = _lib.run_layer(W, self.Xxt_damped, self.L, T0, self.iterations, alias_q=alias)
-        Wq, Losses = _lib.dequant_losses(W, T, Q, torch.diagonal(Hinv).contiguous())
+        Wq, Losses = _lib.dequant_losses(W, T, Q, _hinv_diag(Hinv).contiguous())
         self.ganq_indices = Q          # permuted column order until quantize() un-permutes it
         self.ganq_codebook = T
         self.ganq_stats = {"dists": dists, "best_k": best_k, "enqueue_s": time.perf_counter() - t0}

@@ -112,6 +112,15 @@ class GPTQ:
 
     # ---- gptq.py:238-375 ---------------------------------------------------------------------------------
     @torch.inference_mode()
+    def _needs_only_hinv_diag(self) -> bool:
+        """True when the quantization loop reads nothing of Hinv but its diagonal (GANQ does; see ganq.py)."""
+        return False
+
+    @staticmethod
+    def _hip_cholesky(H):
+        from .. import _lib
+        return _lib.cholesky(H)
+
     def quantize(self, blocksize=128):
         start = time.time()
         for inp in self.fwd_inputs_buffered_data:
@@ -149,9 +158,12 @@ class GPTQ:
             invperm = torch.argsort(perm)
 
         self.Xxt = H.clone()  # undamped
+        # the GANQ loop only reads diag(Hinv), which one factorisation of the index-reversed matrix gives (config.py)
+        native = (getattr(self.qcfg, "ganq_prologue", "torch") == "hip" and self._needs_only_hinv_diag() and H.is_cuda)
+        chol = self._hip_cholesky if native else torch.linalg.cholesky
         if self.qcfg.l_damp_style == "ganq":
             offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
-            self.L = torch.linalg.cholesky(H + torch.diag(offset))
+            self.L = chol(H + torch.diag(offset))
 
         damp_percent = self.qcfg.damp_percent
         Hinv = None
@@ -161,10 +173,16 @@ class GPTQ:
                 diag = torch.arange(self.columns, device=self.device)
                 H[diag, diag] += damp
                 self.Xxt_damped = H.clone()
-                L = torch.linalg.cholesky(H)
-                if self.qcfg.l_damp_style == "gptq":
-                    self.L = L.clone()
-                Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
+                if native:
+                    if self.qcfg.l_damp_style == "gptq":
+                        self.L = chol(H)
+                    Lr = chol(torch.flip(H, dims=(0, 1)))
+                    Hinv = torch.flip(1.0 / torch.diagonal(Lr), dims=(0,)).contiguous()  # 1-D: the diagonal only
+                else:
+                    L = torch.linalg.cholesky(H)
+                    if self.qcfg.l_damp_style == "gptq":
+                        self.L = L.clone()
+                    Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
                 break
             except torch._C._LinAlgError as e:
                 if self.qcfg.damp_auto_increment != 0:

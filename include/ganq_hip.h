@@ -56,6 +56,13 @@ int ganq_debug_div_check(uint64_t count, uint32_t seed, unsigned long long* mism
 int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
                        int64_t batch, void* stream);
 
+/* ---- a2: prologue (gptq.py:280-309) -- lower Cholesky factor A = L L^T in fp32, in place (row-major, leading
+ * dimension lda; the strictly upper triangle is zeroed like torch.linalg.cholesky does).  *info (device int32) is 0
+ * on success or the 1-based column of the first non-positive pivot (the factor then holds NaN); nothing is
+ * synchronised.  workspace: ganq_cholesky_workspace_bytes().                                                   */
+size_t ganq_cholesky_workspace_bytes(int64_t n);
+int ganq_cholesky(float* A, int64_t n, int64_t lda, int32_t* info, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a3: codebook initialisation (ganq.py:423-438, kmeans_fit :27-30) -----------------------
  * Optimal weighted 1-D k-means per row; col_weight [n] fp64 (caller passes diag(Hinv)^-4).
  * T0 [m,V] fp32 ascending per row.  workspace: ganq_kmeans_workspace_bytes().               */

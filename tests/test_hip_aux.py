@@ -64,6 +64,30 @@ def test_hessian_vs_oracle_shapes(hip, oracle, rows, n, dtype):
         assert rel_fro(H.cpu().numpy(), Ho) < 1e-6
 
 
+# ------------------------------------------------------------------------------------------ Cholesky (prologue)
+@pytest.mark.parametrize("n", [1, 5, 127, 128, 129, 300, 1000, 2048])
+def test_cholesky_vs_fp64(hip, n):
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((2 * n + 3, n)) * (0.1 + rng.random(n))
+    H = (X.T @ X / X.shape[0] + 0.01 * np.eye(n)).astype(np.float32)
+    L = hip.cholesky(dev(H)).cpu().numpy()
+    assert np.all(np.triu(L, 1) == 0)
+    ref = np.linalg.cholesky(H.astype(np.float64))
+    assert rel_fro(L, ref) < 2e-6
+    assert rel_fro(L.astype(np.float64) @ L.astype(np.float64).T, H) < 2e-6
+    Lt = torch.linalg.cholesky(dev(H)).cpu().numpy()  # rocSOLVER, fp32: same size of error against fp64
+    assert rel_fro(L, ref) < 4 * max(rel_fro(Lt, ref), 1e-7)
+
+
+def test_cholesky_not_positive_definite_raises(hip):
+    H = np.eye(200, dtype=np.float32)
+    H[150, 150] = -1.0
+    with pytest.raises(torch.linalg.LinAlgError):
+        hip.cholesky(dev(H))
+    L, info = hip.cholesky(dev(H), check=False)
+    assert int(info) == 151
+
+
 # ------------------------------------------------------------------------------------------ k-means
 @pytest.mark.parametrize("m,n,V,seed", [(8, 64, 4, 1), (32, 300, 16, 2), (16, 1024, 8, 3), (5, 4096, 16, 4), (3, 17, 16, 5),
                                         (700, 256, 16, 6), (2, 4700, 16, 7), (2, 4800, 16, 8), (3, 1, 4, 9), (2, 2, 4, 10)])

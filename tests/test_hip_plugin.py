@@ -10,7 +10,7 @@ from conftest import golden_names, load_golden, rel_fro
 pytestmark = pytest.mark.gpu
 
 
-def make_quantizer(g, lin=None):
+def make_quantizer(g, lin=None, prologue="hip"):
     from ganq_amd.looper.named_module import NamedModule
     from ganq_amd.quantization import GANQ, QuantizeConfig
 
@@ -22,16 +22,18 @@ def make_quantizer(g, lin=None):
             lin.bias.copy_(torch.from_numpy(g["bias"]))
     qcfg = QuantizeConfig(bits=int(g["bits"]), quant_method="ganq", format="ganq_lut", act_sort=str(g["act_sort"]),
                           l_damp_style=str(g["l_damp_style"]), dead=str(g["dead"]), desc_act=bool(g["desc_act"]),
-                          ganq_iterations=int(g["K"]), group_size=int(g["group_size"]), damp_percent=0.01)
+                          ganq_iterations=int(g["K"]), group_size=int(g["group_size"]), damp_percent=0.01,
+                          ganq_prologue=prologue)
     q = GANQ(NamedModule(lin, "fc1", "model.layers.0.fc1", 0), qcfg)
     q.quantizer.configure(perchannel=True)
     return q, lin
 
 
+@pytest.mark.parametrize("prologue", ["hip", "torch"])
 @pytest.mark.parametrize("name", golden_names())
-def test_quantize_seven_tuple_vs_reference(name):
+def test_quantize_seven_tuple_vs_reference(name, prologue):
     g = load_golden(name)
-    q, lin = make_quantizer(g)
+    q, lin = make_quantizer(g, prologue=prologue)
     for xb in g["X"]:
         q.add_batch(torch.from_numpy(xb).cuda(), None)
     assert q.nsamples == int(g["nsamples"]) and q.fwd_counter == g["X"].shape[0]
@@ -51,6 +53,24 @@ def test_quantize_seven_tuple_vs_reference(name):
     # what the reference throws away: indices + codebook reproduce the returned weight exactly
     rec = q.ganq_codebook.gather(1, q.ganq_indices.long()).half()
     assert torch.equal(rec, wq)
+
+
+def test_prologue_hip_matches_reference_op_sequence():
+    # ganq_cholesky + diag(Hinv) from the index-reversed factorisation vs cholesky -> cholesky_inverse -> cholesky(upper)
+    from ganq_amd import _lib
+    n = 1536
+    g = torch.Generator(device="cuda").manual_seed(3)
+    X = torch.randn(4 * n, n, device="cuda", generator=g) * (0.1 + torch.rand(n, device="cuda", generator=g))
+    H = (X.T @ X) / X.shape[0]
+    H += 0.01 * H.diag().mean() * torch.eye(n, device="cuda")
+    L = torch.linalg.cholesky(H)
+    ref = torch.diagonal(torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True))
+    Lr = _lib.cholesky(torch.flip(H, dims=(0, 1)))
+    mine = torch.flip(1.0 / torch.diagonal(Lr), dims=(0,))
+    assert float(((mine - ref).abs() / ref.abs()).max()) < 2e-4  # both fp32; the reference's inverse is the noisier one
+    H64 = H.double()
+    exact = torch.diagonal(torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H64)), upper=True))
+    assert float(((mine.double() - exact).abs() / exact).max()) <= 2 * float(((ref.double() - exact).abs() / exact).max()) + 1e-6
 
 
 def test_quantizer_rejects_cpu_module_and_bits8():
