@@ -3,11 +3,12 @@
 // per-weight losses consume the diagonal of the upper factor of H^-1).
 //
 // Blocked right-looking, block 128, three kernels per block column j (everything stays on the stream, no host sync):
-//   chol_diag_kernel   one workgroup: the 128x128 diagonal block is factored in LDS (column by column, IEEE sqrt and
-//                      divide) and its inverse X = L11^-1 is formed by forward substitution, all columns at once;
-//   chol_abt_kernel<0> panel:   L21 = A21 X^T          (one 128-row block per workgroup, in place)
-//   chol_abt_kernel<1> update:  A22 -= L21 L21^T       (lower-triangular 128x128 tiles)
-// Both products are C = A B^T with K = 128 held entirely in LDS, v_mfma_f32_32x32x2_f32, 4 waves x (64x64).
+//   chol_diag_kernel   one workgroup: the 128x128 diagonal block as 4x4 blocks of 32 -- each 32x32 diagonal block is
+//                      factored and inverted by one wave in registers (IEEE sqrt / divide, v_readlane broadcasts),
+//                      the rest of the block follows on the matrix cores;
+//   chol_panel_kernel  panel:   L21 = A21 L11^-T       (block-wise substitution with the four 32x32 inverses)
+//   chol_update_kernel update:  A22 -= L21 L21^T       (lower-triangular 128x128 tiles, K = 128 held in LDS)
+// All products are C = A B^T on v_mfma_f32_32x32x2_f32.
 // A non-positive pivot sets *info (1-based column, like LAPACK) and poisons the factor with NaN; the host wrapper
 // reads info once at the end.
 #include "common.h"
@@ -19,116 +20,202 @@ constexpr int CP = CB + 1;  // LDS row pitch: lanes walking down a column hit di
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CDT = 1024;          // threads of the diagonal-block kernel: its cost is barriers, not arithmetic
-constexpr int CDP = CDT / CB;      // k-range parts per column in the inverse
-__global__ __launch_bounds__(CDT) void chol_diag_kernel(float* __restrict__ A, int64_t lda, int j, int nb,
-                                                         float* __restrict__ Xout, int* __restrict__ info) {
-    extern __shared__ __align__(16) float sm[];
-    float(*S)[CP] = reinterpret_cast<float(*)[CP]>(sm);            // the block, lower part
-    float(*X)[CP] = reinterpret_cast<float(*)[CP]>(sm + CB * CP);  // its inverse
-    __shared__ float red[CDP][CB];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < CB * CB; i += CDT) {
-        const int r = i / CB, c = i % CB;
-        S[r][c] = (r < nb && c <= r) ? A[(int64_t)(j + r) * lda + j + c] : (r == c ? 1.0f : 0.0f);
-        X[r][c] = 0.0f;
-    }
-    const int ty = tid >> 5, tx = tid & 31;
-    for (int c = 0; c < nb; ++c) {
-        __syncthreads();
-        const float d = S[c][c];
-        if (!(d > 0.0f) && tid == 0) atomicCAS(info, 0, j + c + 1);
-        const float dd = sqrtf(d);  // NaN for a negative pivot: the factor is visibly unusable
-        __syncthreads();
-        if (tid == 0) S[c][c] = dd;
-        for (int r = c + 1 + tid; r < nb; r += CDT) S[r][c] = S[r][c] / dd;
-        __syncthreads();
-        // trailing update of the lower triangle: S[r][c2] -= S[r][c] * S[c2][c], c < c2 <= r
-        for (int r = c + 1 + ty; r < nb; r += CDT / 32) {
-            const float lr = S[r][c];
-            for (int c2 = c + 1 + tx; c2 <= r; c2 += 32) S[r][c2] = fmaf(-lr, S[c2][c], S[r][c2]);
-        }
-    }
-    __syncthreads();
-    // X = L^-1 row by row: X[r][r] = 1 / L[r][r], X[r][c] = -(sum_{k=c}^{r-1} L[r][k] X[k][c]) / L[r][r] for c < r.
-    // thread -> (column c = tid % 128, part = tid / 128 of the k range), partial sums meet in LDS.
-    const int xc = tid & (CB - 1), part = tid >> 7;
-    for (int r = 0; r < nb; ++r) {
-        float s = 0.0f;
-        if (xc < r)
-            for (int k = xc + part; k < r; k += CDP) s = fmaf(S[r][k], X[k][xc], s);
-        red[part][xc] = s;
-        __syncthreads();
-        if (part == 0) {
-            const float lrr = S[r][r];
-            if (xc < r) {
-                float t = red[0][xc];
+constexpr int XP = 33;  // pitch of the 32x32 diagonal inverses in LDS
+
+__device__ __forceinline__ float rl(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One wave, 32x32 blocks in LDS: acc (+/-)= A B^T, i.e. C[i][j] += sign * sum_k A[i][k] B[j][k].
+// C layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ void mm32(f32x16& acc, const float* A, int pa, const float* B, int pb, bool neg, int lane) {
+    const int i32 = lane & 31, kk = lane >> 5;
 #pragma unroll
-                for (int p = 1; p < CDP; ++p) t += red[p][xc];
-                X[r][xc] = -t / lrr;
-            } else if (xc == r) {
-                X[r][r] = 1.0f / lrr;
+    for (int k = 0; k < 32; k += 2) {
+        float a = A[i32 * pa + k + kk];
+        const float b = B[i32 * pb + k + kk];
+        if (neg) a = -a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void acc_load(f32x16& acc, const float* C, int pc, int lane) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = C[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * pc + (lane & 31)];
+}
+__device__ __forceinline__ void acc_store(const f32x16& acc, float* C, int pc, int lane) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) C[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * pc + (lane & 31)] = acc[e];
+}
+
+// 128 rows x 128 k of A (row0.., columns j..j+nb) -> LDS block, zero beyond nb / n.  All 16 row segments of a
+// thread are requested before the first is stored: the block comes from L2 / HBM, one round trip instead of 16.
+__device__ __forceinline__ void load_block(float (*dst)[CP], const float* __restrict__ A, int64_t lda, int row0, int nrows_valid,
+                                           int j, int nb, int tid, bool lower_only) {
+    float4 v[16];
+    const int k4 = (tid & 31) * 4;
+    const bool vec = ((lda & 3) == 0) && ((j & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (tid >> 5) + 8 * e;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nrows_valid) {
+            const float* p = A + (int64_t)(row0 + r) * lda + j + k4;
+            if (vec && k4 + 3 < nb) {
+                x = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (k4 + 0 < nb) x.x = p[0];
+                if (k4 + 1 < nb) x.y = p[1];
+                if (k4 + 2 < nb) x.z = p[2];
+                if (k4 + 3 < nb) x.w = p[3];
             }
         }
-        __syncthreads();
+        v[e] = x;
     }
-    for (int i = tid; i < CB * CB; i += CDT) {
-        const int r = i / CB, c = i % CB;
-        if (r < nb && c < nb) A[(int64_t)(j + r) * lda + j + c] = (c <= r) ? S[r][c] : 0.0f;
-        Xout[i] = (r < nb && c < nb) ? X[r][c] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (tid >> 5) + 8 * e;
+        float w[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[r][k4 + t] = (lower_only && k4 + t > r) ? 0.0f : w[t];
     }
 }
 
-// MODE 0 (panel):  rows R0 + 128*blockIdx.x .. : A21[rows][j:j+nb] <- A21 X^T            (X = Xin, 128x128 row-major)
-// MODE 1 (update): tile (bi >= bj) of the trailing matrix at R0: A22[bi][bj] -= L21[bi] L21[bj]^T
-template <int MODE>
-__global__ __launch_bounds__(256) void chol_abt_kernel(float* __restrict__ A, int64_t lda, int n, int j, int nb,
-                                                       const float* __restrict__ Xin) {
+// Diagonal 128x128 block as 4x4 blocks of 32.  Per block column kb: wave 0 factors the 32x32 diagonal block with one
+// row per lane in registers (pivot / column broadcasts are v_readlane, no LDS round trips) and inverts it the same
+// way (one column of the inverse per lane); the blocks below are multiplied by that inverse and the trailing blocks
+// updated on the matrix cores.  Only the four 32x32 inverses leave the kernel: the panel kernel solves block-wise.
+__global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, int64_t lda, int j, int nb,
+                                                        float* __restrict__ Xout, int* __restrict__ info) {
+    extern __shared__ __align__(16) float sm[];
+    float(*S)[CP] = reinterpret_cast<float(*)[CP]>(sm);  // the block, lower part
+    float* Xd = sm + CB * CP;                              // [4][32][XP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < CB * CB; i += 256) {
+        const int r = i / CB, c = i % CB;
+        S[r][c] = (r < nb && c <= r) ? A[(int64_t)(j + r) * lda + j + c] : (r == c ? 1.0f : 0.0f);
+    }
+    __syncthreads();
+    for (int kb = 0; kb < 4; ++kb) {
+        if (wv == 0) {
+            const int r = lane & 31;  // lanes 32..63 mirror 0..31 (their results are not stored)
+            float a[32], x[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) a[c] = S[32 * kb + r][32 * kb + c];
+            int bad = 0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const float d = rl(a[c], c);
+                if (!(d > 0.0f) && bad == 0) bad = 32 * kb + c + 1;
+                const float dd = sqrtf(d);  // NaN for a negative pivot: the factor is visibly unusable
+                const float l = (r == c) ? dd : a[c] / dd;
+                a[c] = l;
+#pragma unroll
+                for (int c2 = c + 1; c2 < 32; ++c2) a[c2] = fmaf(-l, rl(l, c2), a[c2]);
+            }
+            if (bad && lane == 0) atomicCAS(info, 0, j + bad);
+            // inverse, lane = column: x[q] = (delta - sum_{k<q} L[q][k] x[k]) / L[q][q]
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                float sacc = (r == q) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int k = 0; k < q; ++k) sacc = fmaf(-rl(a[k], q), x[k], sacc);
+                x[q] = sacc / rl(a[q], q);
+            }
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    S[32 * kb + r][32 * kb + c] = (c <= r) ? a[c] : 0.0f;
+                    Xd[(kb * 32 + c) * XP + r] = x[c];  // X[row c][col r]
+                }
+            }
+        }
+        __syncthreads();
+        if (kb + 1 + wv <= 3) {  // panel: S[i][kb] <- S[i][kb] X_kb^T
+            const int i = kb + 1 + wv;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            mm32(acc, &S[32 * i][32 * kb], CP, Xd + kb * 32 * XP, XP, false, lane);
+            wsync();
+            acc_store(acc, &S[32 * i][32 * kb], CP, lane);
+        }
+        __syncthreads();
+        int p = 0;
+        for (int i = kb + 1; i < 4; ++i)
+            for (int jb = kb + 1; jb <= i; ++jb, ++p) {
+                if ((p & 3) != wv) continue;
+                f32x16 acc;
+                acc_load(acc, &S[32 * i][32 * jb], CP, lane);
+                mm32(acc, &S[32 * i][32 * kb], CP, &S[32 * jb][32 * kb], CP, true, lane);
+                acc_store(acc, &S[32 * i][32 * jb], CP, lane);
+            }
+        __syncthreads();
+    }
+    for (int i = tid; i < CB * CB; i += 256) {
+        const int r = i / CB, c = i % CB;
+        if (r < nb && c < nb) A[(int64_t)(j + r) * lda + j + c] = (c <= r) ? S[r][c] : 0.0f;
+    }
+    for (int i = tid; i < 4 * 32 * 32; i += 256) Xout[i] = Xd[(i >> 5) * XP + (i & 31)];
+}
+
+// Panel: rows R0 + 128*blockIdx.x ..: L21 = A21 L11^-T, block-wise forward substitution with the 32x32 inverses:
+//   L21[:, kb] = (A21[:, kb] - sum_{k < kb} L21[:, k] L11[kb][k]^T) X_kb^T.  Every wave owns 32 rows; no block barriers.
+__global__ __launch_bounds__(256) void chol_panel_kernel(float* __restrict__ A, int64_t lda, int n, int j, int nb,
+                                                         const float* __restrict__ Xin) {
+    extern __shared__ __align__(16) float sm[];
+    float(*Ab)[CP] = reinterpret_cast<float(*)[CP]>(sm);
+    float(*L11)[CP] = reinterpret_cast<float(*)[CP]>(sm + CB * CP);
+    float* Xd = sm + 2 * CB * CP;  // [4][32][XP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r0 = j + nb + CB * blockIdx.x;
+    load_block(Ab, A, lda, r0, min(CB, n - r0), j, nb, tid, false);
+    load_block(L11, A, lda, j, nb, j, nb, tid, true);
+    for (int i = tid; i < 4 * 32 * 32; i += 256) Xd[(i >> 5) * XP + (i & 31)] = Xin[i];
+    __syncthreads();
+    for (int kb = 0; kb < 4; ++kb) {
+        f32x16 acc;
+        acc_load(acc, &Ab[32 * wv][32 * kb], CP, lane);
+        for (int k = 0; k < kb; ++k) mm32(acc, &Ab[32 * wv][32 * k], CP, &L11[32 * kb][32 * k], CP, true, lane);
+        wsync();
+        acc_store(acc, &Ab[32 * wv][32 * kb], CP, lane);
+        wsync();
+        f32x16 out;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[e] = 0.0f;
+        mm32(out, &Ab[32 * wv][32 * kb], CP, Xd + kb * 32 * XP, XP, false, lane);
+        wsync();
+        acc_store(out, &Ab[32 * wv][32 * kb], CP, lane);
+        wsync();
+    }
+    __syncthreads();
+    for (int i = tid; i < CB * CB; i += 256) {
+        const int r = i / CB, c = i % CB;
+        if (r0 + r < n && c < nb) A[(int64_t)(r0 + r) * lda + j + c] = Ab[r][c];
+    }
+}
+
+// Update: tile (bi >= bj) of the trailing matrix at R0 = j + nb: A22[bi][bj] -= L21[bi] L21[bj]^T, K = nb <= 128 held
+// entirely in LDS, 4 waves x (64x64).
+__global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ A, int64_t lda, int n, int j, int nb) {
     extern __shared__ __align__(16) float sm[];
     float(*As)[CP] = reinterpret_cast<float(*)[CP]>(sm);
     float(*Bs)[CP] = reinterpret_cast<float(*)[CP]>(sm + CB * CP);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R0 = j + nb;  // first row / column of the trailing part
-    int bi, bj;
-    if (MODE == 0) {
-        bi = blockIdx.x;
-        bj = 0;
-    } else {
-        // linear index -> (bi, bj) with bj <= bi
-        const int t = blockIdx.x;
-        int b = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while ((b + 1) * (b + 2) / 2 <= t) ++b;
-        while (b * (b + 1) / 2 > t) --b;
-        bi = b;
-        bj = t - b * (b + 1) / 2;
-    }
+    // linear index -> (bi, bj) with bj <= bi
+    const int t = blockIdx.x;
+    int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
     const int ra0 = R0 + CB * bi, rb0 = R0 + CB * bj;
     // stage the operands: 128 rows x 128 k each (k beyond nb and rows beyond n are zero)
-    for (int i = tid; i < CB * (CB / 4); i += 256) {
-        const int r = i / (CB / 4), k4 = (i % (CB / 4)) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ra0 + r < n) {
-            const float* p = A + (int64_t)(ra0 + r) * lda + j + k4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k4 + e < nb) v[e] = p[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) As[r][k4 + e] = v[e];
-        float w[4] = {0.f, 0.f, 0.f, 0.f};
-        if (MODE == 0) {
-            const float* p = Xin + (int64_t)r * CB + k4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = p[e];
-        } else if (rb0 + r < n) {
-            const float* p = A + (int64_t)(rb0 + r) * lda + j + k4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k4 + e < nb) w[e] = p[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[r][k4 + e] = w[e];
-    }
+    load_block(As, A, lda, ra0, max(0, min(CB, n - ra0)), j, nb, tid, false);
+    load_block(Bs, A, lda, rb0, max(0, min(CB, n - rb0)), j, nb, tid, false);
     __syncthreads();
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
     const int i32 = lane & 31, kk = lane >> 5;
@@ -161,14 +248,10 @@ __global__ __launch_bounds__(256) void chol_abt_kernel(float* __restrict__ A, in
                 const int cc = wn + 32 * b + i32;
                 const int row = ra0 + rr;
                 if (row >= n) continue;
-                if (MODE == 0) {
-                    if (cc < nb) A[(int64_t)row * lda + j + cc] = acc[a][b][e];
-                } else {
-                    const int col = rb0 + cc;
-                    if (col < n && col <= row) {
-                        float* p = A + (int64_t)row * lda + col;
-                        *p = *p - acc[a][b][e];
-                    }
+                const int col = rb0 + cc;
+                if (col < n && col <= row) {
+                    float* p = A + (int64_t)row * lda + col;
+                    *p = *p - acc[a][b][e];
                 }
             }
 }
@@ -202,13 +285,15 @@ extern "C" int ganq_cholesky(float* A, int64_t n, int64_t lda, int32_t* info_out
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* X = static_cast<float*>(workspace);
     const size_t smem = 2 * (size_t)CB * CP * sizeof(float);
+    const size_t smem_diag = ((size_t)CB * CP + 4 * 32 * XP) * sizeof(float);
+    const size_t smem_panel = (2 * (size_t)CB * CP + 4 * 32 * XP) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_abt_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_abt_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_diag));
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_panel));
+        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_update_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;
     }
@@ -216,13 +301,13 @@ extern "C" int ganq_cholesky(float* A, int64_t n, int64_t lda, int32_t* info_out
     GANQ_HIP_CHECK(hipMemsetAsync(info_out, 0, sizeof(int32_t), stream));
     for (int64_t j = 0; j < n; j += CB) {
         const int nb = (int)std::min<int64_t>(CB, n - j);
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(CDT), smem, stream, A, lda, (int)j, nb, X, info_out);
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), smem_diag, stream, A, lda, (int)j, nb, X, info_out);
         const int64_t rem = n - j - nb;
         if (rem > 0) {
             const int nblk = (int)((rem + CB - 1) / CB);
-            hipLaunchKernelGGL(chol_abt_kernel<0>, dim3(nblk), dim3(256), smem, stream, A, lda, (int)n, (int)j, nb, X);
-            hipLaunchKernelGGL(chol_abt_kernel<1>, dim3(nblk * (nblk + 1) / 2), dim3(256), smem, stream, A, lda, (int)n,
-                               (int)j, nb, X);
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), smem_panel, stream, A, lda, (int)n, (int)j, nb, X);
+            hipLaunchKernelGGL(chol_update_kernel, dim3(nblk * (nblk + 1) / 2), dim3(256), smem, stream, A, lda, (int)n,
+                               (int)j, nb);
         }
     }
     hipLaunchKernelGGL(chol_zero_upper_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, stream, A, lda, (int)n);
