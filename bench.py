@@ -109,8 +109,10 @@ def build_workload(args, dist, dev):
 
 
 def cpu_baseline(cap, args):
-    """the reference's own op sequence (torch CPU: per-column gather + gemv, lstsq/gelsd, quad loss) on a bounded
-    sample: `rows` rows of the same layer, one iteration; rows are independent, so layer time scales by m/rows."""
+    """CPU figures for the same loop on the box's host cores, on a bounded sample (rows are independent, so layer time
+    scales by m/rows; one of the K iterations is timed).  Headline: the C restatement with OpenMP (the faster and
+    steadier of the two); next to it the reference's own op sequence on torch CPU (per-column gather + gemv,
+    lstsq/gelsd, quad loss), which is what a user of the reference runs."""
     from oracle import c_oracle, ganq_ref
 
     threads = max(1, min(os.cpu_count() or 1, 16))
@@ -123,22 +125,23 @@ def cpu_baseline(cap, args):
     ganq_ref.run_layer(W, H, L, T0, 1, timings=timings)
     t_ref = time.perf_counter() - t0
     per_layer = t_ref * (args.m / rows) * args.iters
-    out = {"value": round(args.n / per_layer, 4), "unit": "columns/s", "cores": threads, "kind": "port",
-           "sample": f"torch op-sequence restatement of ganq.py:533-626 (oracle/ganq_ref.py), {rows} of {args.m} rows x "
-                     f"1 of {args.iters} iterations of the same {args.m}x{args.n} layer, {t_ref:.2f} s measured "
-                     f"(S-solve {timings[0][0]:.2f} s, T-update {timings[0][1]:.2f} s, loss {timings[0][2]:.2f} s), scaled "
-                     f"by rows and iterations",
-           "measured_s": round(t_ref, 3)}
-    # second, stronger CPU number: the canonical-order C oracle with OpenMP
+    torch_seq = {"value": round(args.n / per_layer, 4), "unit": "columns/s", "cores": threads,
+                 "sample": f"torch op-sequence restatement of ganq.py:533-626 (oracle/ganq_ref.py), {rows} of {args.m} rows x "
+                           f"1 of {args.iters} iterations of the same {args.m}x{args.n} layer, {t_ref:.2f} s measured "
+                           f"(S-solve {timings[0][0]:.2f} s, T-update {timings[0][1]:.2f} s, loss {timings[0][2]:.2f} s), "
+                           f"scaled by rows and iterations",
+                 "measured_s": round(t_ref, 3)}
     c_oracle.set_num_threads(threads)
     rows_c = min(4 * rows, args.m)
     Wn, Hn, Ln, Tn = cap["W"][:rows_c].cpu().numpy(), H.numpy(), L.numpy(), cap["T0"][:rows_c].cpu().numpy()
     t0 = time.perf_counter()
     c_oracle.run_layer(Wn, Hn, Ln, Tn, 1)
     t_c = time.perf_counter() - t0
-    out["c_oracle"] = {"value": round(args.n / (t_c * (args.m / rows_c) * args.iters), 4), "unit": "columns/s",
-                       "cores": threads, "sample": f"oracle/ganq_oracle.c, {rows_c} rows x 1 iteration, {t_c:.2f} s"}
-    return out
+    return {"value": round(args.n / (t_c * (args.m / rows_c) * args.iters), 4), "unit": "columns/s", "cores": threads,
+            "kind": "port",
+            "sample": f"oracle/ganq_oracle.c (OpenMP, {threads} threads), {rows_c} of {args.m} rows x 1 of {args.iters} iterations "
+                      f"of the same {args.m}x{args.n} layer, {t_c:.2f} s measured, scaled by rows and iterations",
+            "measured_s": round(t_c, 3), "torch_op_sequence": torch_seq}
 
 
 def main():
@@ -225,11 +228,11 @@ def main():
         roof["frac"] = round(roof["achieved"] / roof["peak"], 5)
         roof["avg_launch_ms"] = round(dom_ms / dom_cnt, 4)
         # HBM bytes per launch from the PMC counters of a separate rocprofv3 --pmc pass over the same kernels
-        # (profiles/r01_pmc_traffic_v3.json, tools/pmc_collect.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+        # (profiles/r01_pmc_traffic_v4.json, tools/pmc_collect.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
         # for gfx950)
         roof["traffic"] = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v3.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v4.json")))
             for k, v in pmc.items():
                 if k.split("<")[0] == dom_name and (m, n) == (4096, 4096):
                     roof["traffic"] = int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
