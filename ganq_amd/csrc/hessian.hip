@@ -8,6 +8,12 @@
 // TOKENS per lane, which ds_read_b64_tr_b16 delivers straight from that layout (hardware transpose).
 // Only tiles on or below the diagonal are computed; the mirror image is written from the same registers,
 // so H is exactly symmetric.
+#include <algorithm>
+#include <mutex>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 namespace ganq {
@@ -32,20 +38,25 @@ __device__ __forceinline__ f32x16 mfma16(s8v a, s8v b, f32x16 c) {
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows,
-                                                      int n, float decay, float scale, int tiles_per_side) {
-    __shared__ __align__(16) uint16_t Xa[2][HK][HP];
-    __shared__ __align__(16) uint16_t Xb[2][HK][HP];
+                                                      int n, float decay, float scale, int tiles_per_side,
+                                                      const uint32_t* __restrict__ tile_order) {
+    __shared__ __align__(16) uint16_t Xs[2][2][HK][HP];  // [operand][buffer][token][feature]; reused by the epilogue
+    uint16_t(*Xa)[HK][HP] = Xs[0];
+    uint16_t(*Xb)[HK][HP] = Xs[1];
 
-    // blockIdx.x enumerates the lower-triangular tile pairs (tu >= tv)
+    // blockIdx.x enumerates the lower-triangular tile pairs (tu >= tv) through a table in Z (Morton) order, and the
+    // workgroups an XCD receives (every 8th) are mapped to one contiguous run of it: the 32 CUs behind one L2 then work
+    // on a compact patch of H that needs ~16 of the 32 column blocks of X instead of all of them, which keeps the
+    // token slabs they stream L2-resident even when the workgroups drift apart (PMC: 62 % L2 hits, 230 MB fetched per
+    // 2048-token batch of a 16 MB X before this).
     int tu = 0, tv = 0;
     {
         int b = blockIdx.x;
-        // row-major over the triangle: tile row tu has tu+1 entries
-        int r = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
-        while ((r + 1) * (r + 2) / 2 <= b) ++r;
-        while (r * (r + 1) / 2 > b) --r;
-        tu = r;
-        tv = b - r * (r + 1) / 2;
+        const int nblk = (int)gridDim.x;
+        if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
+        const uint32_t pr = tile_order[b];
+        tu = (int)(pr >> 16);
+        tv = (int)(pr & 0xffffu);
     }
     (void)tiles_per_side;
     const int u0 = tu * HT, v0 = tv * HT;
@@ -53,36 +64,41 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
 
     // staging: slab = 32 tokens x 128 features = 512 x 16 B per operand, 2 per thread
-    uint4 ra[2], rb[2];
-    auto gload = [&](int t0) {
+    // four slabs of registers in rotation: the loads of slab s+3 are issued while slab s is multiplied (a slab's 64
+    // MFMA-cycles are far shorter than one trip to L2 / HBM, and a tile is a chain of rows/32 such trips)
+    uint4 ra4[4][2], rb4[4][2];
+    // fast path (uniform per workgroup): full, 16-byte aligned tile columns -> unconditional loads (a token row past
+    // the end is clamped and zeroed afterwards), so that the compiler can count the loads in flight instead of
+    // draining them at every slab
+    const bool fast = (u0 + HT <= n) && (v0 + HT <= n) && ((n & 7) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    auto gload = [&](auto fast_tag, int t0, uint4 (&ra)[2], uint4 (&rb)[2]) {
+        constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int idx = h * 256 + tid;
             const int t = t0 + (idx >> 4), f8 = (idx & 15) * 8;
             uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-            if (t < rows) {
+            if constexpr (FAST) {
+                const int tc = min(t, rows - 1);
+                va = *reinterpret_cast<const uint4*>(X + (int64_t)tc * n + u0 + f8);
+                vb = *reinterpret_cast<const uint4*>(X + (int64_t)tc * n + v0 + f8);
+                if (t >= rows) va = vb = make_uint4(0, 0, 0, 0);
+            } else {
+              if (t < rows) {
                 const uint16_t* pa = X + (int64_t)t * n + u0 + f8;
                 const uint16_t* pb = X + (int64_t)t * n + v0 + f8;
-                if (u0 + f8 + 7 < n && ((reinterpret_cast<uintptr_t>(pa) & 15) == 0)) {
-                    va = *reinterpret_cast<const uint4*>(pa);
-                } else {
-                    uint16_t tmp[8];
-                    for (int e = 0; e < 8; ++e) tmp[e] = (u0 + f8 + e < n) ? pa[e] : (uint16_t)0;
-                    va = *reinterpret_cast<uint4*>(tmp);
-                }
-                if (v0 + f8 + 7 < n && ((reinterpret_cast<uintptr_t>(pb) & 15) == 0)) {
-                    vb = *reinterpret_cast<const uint4*>(pb);
-                } else {
-                    uint16_t tmp[8];
-                    for (int e = 0; e < 8; ++e) tmp[e] = (v0 + f8 + e < n) ? pb[e] : (uint16_t)0;
-                    vb = *reinterpret_cast<uint4*>(tmp);
-                }
+                uint16_t tmp[8];
+                for (int e = 0; e < 8; ++e) tmp[e] = (u0 + f8 + e < n) ? pa[e] : (uint16_t)0;
+                va = *reinterpret_cast<uint4*>(tmp);
+                for (int e = 0; e < 8; ++e) tmp[e] = (v0 + f8 + e < n) ? pb[e] : (uint16_t)0;
+                vb = *reinterpret_cast<uint4*>(tmp);
+              }
             }
             ra[h] = va;
             rb[h] = vb;
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const uint4 (&ra)[2], const uint4 (&rb)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int idx = h * 256 + tid;
@@ -112,12 +128,7 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
     };
 
     const int nslab = (rows + HK - 1) / HK;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nslab) gload((s + 1) * HK);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < HK; kk += 16) {
             s8v a[2], b[2];
@@ -130,10 +141,28 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<BF16>(a[i], b[j], acc[i][j]);
         }
-        if (s + 1 < nslab) sstore(buf ^ 1);
+    };
+    auto mainloop = [&](auto fast_tag) {
+        gload(fast_tag, 0, ra4[0], rb4[0]);
+        gload(fast_tag, HK, ra4[1], rb4[1]);
+        gload(fast_tag, 2 * HK, ra4[2], rb4[2]);
+        sstore(0, ra4[0], rb4[0]);
         __syncthreads();
-    }
+        // whole rounds of four slabs; slabs past the end are zeros (they add nothing)
+        for (int s = 0; s < nslab; s += 4) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                gload(fast_tag, (s + jj + 3) * HK, ra4[(jj + 3) & 3], rb4[(jj + 3) & 3]);
+                compute((s + jj) & 1);
+                sstore((s + jj + 1) & 1, ra4[(jj + 1) & 3], rb4[(jj + 1) & 3]);
+                __syncthreads();
+            }
+        }
+    };
+    if (fast) mainloop(std::true_type{});
+    else mainloop(std::false_type{});
 
+    // direct tile: H[u][v], lanes along v (128 B runs), read-modify-write with the running-average decay
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -142,19 +171,86 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
             for (int r = 0; r < 16; ++r) {
                 const int u = u0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int v = v0 + wn + 32 * j + (lane & 31);
-                if (u < n && v < n && (tu != tv || u >= v)) {
+                float val = 0.0f;
+                if (u < n && v < n) {
                     const int64_t o = (int64_t)u * n + v;
                     const float old = (decay != 0.0f) ? H[o] * decay : 0.0f;
-                    const float val = old + scale * acc[i][j][r];
-                    H[o] = val;
-                    if (u != v) H[(int64_t)v * n + u] = val;
+                    val = old + scale * acc[i][j][r];
+                    H[o] = val;  // a diagonal tile is computed in full (X^T X is symmetric), so it needs no mirror
                 }
+                acc[i][j][r] = val;
             }
+    if (tu == tv) return;
+    // mirror tile H[v][u]: transposed through LDS (the slab buffers are free now) so that it is written in 128 B
+    // runs as well -- as 4-byte scattered stores it cost more than everything else in the kernel together
+    __syncthreads();
+    float(*Tr)[65] = reinterpret_cast<float(*)[65]>(reinterpret_cast<char*>(&Xs[0][0][0][0]) + wv * (32 * 65 * sizeof(float)));
+    static_assert(4 * 32 * 65 * sizeof(float) <= sizeof(Xs), "transpose scratch must fit the slab buffers");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tr[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][32 * j + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int rr = lane & 31;
+        const int u = u0 + wm + 32 * i + rr;
+        for (int cc = lane >> 5; cc < 64; cc += 2) {
+            const int v = v0 + wn + cc;
+            if (u < n && v < n) H[(int64_t)v * n + u] = Tr[rr][cc];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 }  // namespace ganq
 
 using namespace ganq;
+
+namespace {
+struct TileTable {
+    int device, tiles;
+    uint32_t* dev;
+};
+std::vector<TileTable> g_tables;
+std::mutex g_tables_mu;
+
+uint32_t morton2(uint32_t x, uint32_t y) {
+    auto spread = [](uint32_t v) {
+        v &= 0xffffu;
+        v = (v | (v << 8)) & 0x00ff00ffu;
+        v = (v | (v << 4)) & 0x0f0f0f0fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1);
+}
+
+// lower-triangular tile pairs (tu << 16 | tv) sorted along the Z curve; cached per device and tile count
+const uint32_t* tile_table(int tiles, hipStream_t stream) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    for (const TileTable& t : g_tables)
+        if (t.device == device && t.tiles == tiles) return t.dev;
+    std::vector<std::pair<uint32_t, uint32_t>> keyed;
+    for (int tu = 0; tu < tiles; ++tu)
+        for (int tv = 0; tv <= tu; ++tv) keyed.push_back({morton2((uint32_t)tv, (uint32_t)tu), ((uint32_t)tu << 16) | (uint32_t)tv});
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<uint32_t> host(keyed.size());
+    for (size_t i = 0; i < keyed.size(); ++i) host[i] = keyed[i].second;
+    uint32_t* dev = nullptr;
+    if (hipMalloc(&dev, host.size() * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    // synchronous copy on purpose (pageable host memory, once per shape); the stream argument is only ordered after it
+    if (hipMemcpy(dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    (void)stream;
+    g_tables.push_back({device, tiles, dev});
+    return dev;
+}
+}  // namespace
 
 extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
                                   int64_t batch, void* stream_) {
@@ -169,13 +265,15 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
     const float scale = (float)(2.0 / total);
     const int tiles = (int)((n + HT - 1) / HT);
     const int blocks = tiles * (tiles + 1) / 2;
+    const uint32_t* order = tile_table(tiles, stream);
+    if (!order) return fail(-100, "ganq_hessian_accum: could not build the tile table");
     ProfScope prof(KID_HESSIAN, stream);
     if (dtype == 1) {
         hipLaunchKernelGGL(hessian_kernel<true>, dim3(blocks), dim3(256), 0, stream, H, static_cast<const uint16_t*>(X),
-                           (int)rows, (int)n, decay, scale, tiles);
+                           (int)rows, (int)n, decay, scale, tiles, order);
     } else {
         hipLaunchKernelGGL(hessian_kernel<false>, dim3(blocks), dim3(256), 0, stream, H, static_cast<const uint16_t*>(X),
-                           (int)rows, (int)n, decay, scale, tiles);
+                           (int)rows, (int)n, decay, scale, tiles, order);
     }
     GANQ_LAUNCH_CHECK();
     return 0;
