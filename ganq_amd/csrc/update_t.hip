@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void q_diff_kernel(const uint8_t* __restrict__
 // No S_e depends on F or on another S, so the steps run in parallel and add into the row's F with LDS atomics.
 // S_e is a 16-bucket histogram of one row of Hint: lane-private buckets in LDS ([bucket][lane]: no conflicts), then
 // a transposed read sums each bucket over the lanes; the second sum is just 2 more entries per earlier change.
-constexpr int MU_WAVES = 8;
+constexpr int MU_WAVES = 4;  // 4096x4096 benchmark layer: 2 -> 0.224, 4 -> 0.210, 8 -> 0.250 ms per iteration
 __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __restrict__ Hint, const uint8_t* __restrict__ Q,
                                                                 uint8_t* __restrict__ Qprev, int m, int n,
                                                                 const uint16_t* __restrict__ chg, const int* __restrict__ chgcnt,
