@@ -5,6 +5,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "solve_s.h"
 #include "update_t.h"
 
 namespace ganq {
@@ -99,6 +100,8 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
     if (m == 0 || n == 0 || K == 0) return 0;
     if (V < 2 || V > 16) return fail(-2, "ganq_run_layer: V=%d not supported (bits 2..4 are implemented)", V);
     if (!W || !H || !L || !T0 || !T_best || !Q_out || !dists || !best_k) return fail(-3, "ganq_run_layer: null pointer");
+    if (ldl < n) return fail(-1, "ganq_run_layer: ldl=%lld < n=%lld", (long long)ldl, (long long)n);
+    if (n > 16384) return fail(-1, "ganq_run_layer: n=%lld > 16384 not supported", (long long)n);
     const RunLayout lo = run_layout(m, n, V);
     if (!workspace || workspace_bytes < lo.total)
         return fail(-4, "ganq_run_layer: workspace %zu B < required %zu B", workspace_bytes, lo.total);
@@ -123,8 +126,10 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
     hipLaunchKernelGGL(best_init_kernel, dim3(1), dim3(1), 0, stream, best, best_k, flag);
     GANQ_LAUNCH_CHECK();
 
+    rc = solve_s_pack_l(L, ldl, m, n, ws + lo.off_solve, stream);  // L is the same in every iteration
+    if (rc) return rc;
     for (int k = 0; k < K; ++k) {
-        rc = ganq_solve_s(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, lo.solve_bytes, stream_);
+        rc = solve_s_launch(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, stream);
         if (rc) return rc;
         // new codebook and, from the same A and b, the loss of (new codebook, these indices)  (ganq.py:589-591, :621-622)
         rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, dists + k, k, stream);

@@ -18,13 +18,13 @@
 #include <utility>
 
 #include "common.h"
+#include "solve_s.h"
 
 namespace ganq {
 
 constexpr int SB = 64;   // panel width (columns)
 constexpr int SR = 16;   // rows per workgroup
-constexpr int SPF = 16;  // k-groups per prefetch batch
-constexpr int SOLVE_LDS_COLS = 1792;  // columns of Err kept in LDS (112 KB next to the 46 KB of panel buffers)
+constexpr int SOLVE_LDS_PANELS = 28;  // packed Err blocks kept in LDS (28 x 4 KB = 112 KB next to the 46 KB of panel buffers)
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t x) {
@@ -117,27 +117,58 @@ __device__ __forceinline__ void panel_all(PanelState& st, const float4 (*Ld)[16]
 //   registers) and publish R for panel b.  The chain of an output is still ONE accumulator running over the columns
 //   in descending order -- only who computes when has changed.  G also stages the next panel's triangle of L and
 //   its diagonal (double-buffered), P prefetches its next W columns.
-#ifdef GANQ_SOLVE_DEBUG
-__device__ unsigned long long ss_dbg[8];
-#define SS_T() __builtin_amdgcn_s_memtime()
-#define SS_ADD(slot, t0, who) do { if (tid == (who)) atomicAdd(&ss_dbg[slot], __builtin_amdgcn_s_memtime() - (t0)); } while (0)
-#else
-#define SS_T() 0ull
-#define SS_ADD(slot, t0, who) do {} while (0)
-#endif
-// keeps a batch of loads where it was written: the memory clobber stops IR-level load motion across stage boundaries,
-// the sched_barrier stops the machine scheduler
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// keeps a stage of the chain loop where it was written: the memory clobber stops IR-level load motion across stage
+// boundaries, the sched_barrier stops the machine scheduler
 #define GANQ_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-template <bool KASC, int DBG = 0>
+
+// ---------------------------------------------------------------------------------------------------------------
+// Packed operand blocks.  The chain consumes, per (source panel p of 64 columns, 16-wide output tile), 16 k-groups of
+// 4 columns; lane (ksub = lane >> 4, c16 = lane & 15) of the MFMA needs for k-group g the element with
+// u = 64 p + 4 g + kslot(ksub).  A block stores those 16 values of a lane contiguously:
+//     block[(g >> 2) * 256 + lane * 4 + (g & 3)]   (1024 floats = 4 KB; each of the four 16-byte loads of a wave reads
+//                                                   1 KB contiguously, and LDS reads of it are bank-conflict free)
+//   B blocks (L):   Lr[(p * NT + ct) * 1024 + ..] = L[u][16 ct + c16]     built once per L by l_pack_kernel
+//   A blocks (Err): ErrT[tile][p * 1024 + ..]     = Err[row c16][u]      written by the P waves
+// so a batch of 16 MFMAs costs 4 + 4 sixteen-byte loads instead of 16 + 16 dword loads: the lone G wave of a SIMD
+// shares its issue slots with the P wave, and every instruction saved there is matrix-core time gained.
+__global__ __launch_bounds__(64) void l_pack_kernel(const float* __restrict__ L, int64_t ldl, int n, int NT, bool kasc,
+                                                    float* __restrict__ Lr) {
+    const int ct = blockIdx.x, p = blockIdx.y;
+    if (4 * p <= ct - (ct & 3)) return;  // only source panels strictly right of the tile's panel are ever read
+    const int lane = threadIdx.x, c16 = lane & 15, ksub = lane >> 4;
+    const int kslot = kasc ? (3 - ksub) : ksub;
+    const int col = 16 * ct + c16;
+    f32x4v out[4];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int u = 64 * p + 4 * g + kslot;
+        out[g >> 2][g & 3] = (u < n && col < n) ? L[(int64_t)u * ldl + col] : 0.0f;
+    }
+    f32x4v* dst = reinterpret_cast<f32x4v*>(Lr + ((int64_t)p * NT + ct) * 1024 + lane * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j * 64] = out[j];
+}
+
+// Two roles per workgroup (8 waves, one of each role per SIMD):
+//   waves 0-3 (P) run the sequential steps of panel b+1 while
+//   waves 4-7 (G) run the residual chain of panel b over every column right of panel b+1 (part 1); after the barrier
+//   the G waves append the 64 columns of panel b+1 (part 2: Err handed over in LDS, the L block prefetched into
+//   registers) and publish R for panel b.  The chain of an output is still ONE accumulator running over the columns
+//   in descending order -- only who computes when has changed.  G also stages the next panel's triangle of L and
+//   its diagonal (double-buffered), P prefetches its next W columns.
+template <bool KASC>
 __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ W, const float* __restrict__ L,
-                                                      int64_t ldl, const float* __restrict__ T, int m, int n, int V,
+                                                      int64_t ldl, const float* __restrict__ Lr, int NT,
+                                                      const float* __restrict__ T, int m, int n, int V,
                                                       uint8_t* __restrict__ Q, float* __restrict__ ErrOut,
-                                                      float* __restrict__ ErrT, int cbase) {
+                                                      float* __restrict__ ErrT, int pbase) {
     __shared__ float4 Ld[2][SB][16];      // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
     __shared__ float Rp[2][SR][SB + 4];   // residual panel handed from (G) to (P)
     __shared__ float2 Dg[2][SB];          // {L[j][j], 1 / L[j][j]} of the panel's columns
-    __shared__ float ErrP[SB][SR];        // Err of the panel just solved, [col][row] (zero beyond the panel's width)
-    extern __shared__ __align__(16) float ErrL[];  // [n - cbase][SR]: Err of the columns >= cbase, the A operand's hot part
+    __shared__ __align__(16) float ErrPk[1024];  // packed Err block of the panel just solved (zero beyond its width)
+    extern __shared__ __align__(16) float ErrL[];  // packed Err blocks of the panels >= pbase, the A operand's hot part
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -151,24 +182,30 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
     const int prow_in_tile = 4 * gw + rsub;  // row handled by this 16-lane group in phase (P)
     const int prow = min(tile * SR + prow_in_tile, m - 1);
     const bool prow_ok = tile * SR + prow_in_tile < m;
-    float* __restrict__ errt = ErrT + (int64_t)tile * n * SR;
+    const int nb = (n + SB - 1) / SB;
+    float* __restrict__ errt = ErrT + (int64_t)tile * nb * 1024;
 
     PanelState st;
     st.c16 = (uint32_t)c16;
     st.tv = (c16 < V) ? T[(int64_t)prow * V + c16] : __builtin_inff();
     float wnext[4] = {0.f, 0.f, 0.f, 0.f};
 
-    const int ksub = lane >> 4;
-    const int kslot = KASC ? (3 - ksub) : ksub;  // column inside a k-group handled by this lane's MFMA slice
-    const uint32_t laneA = (uint32_t)(kslot * SR + c16);
+    // (P) where this lane's four Err values go inside a packed block: column col = c16 + 16 k is k-group col >> 2,
+    // slot col & 3, i.e. MFMA lane (ksub, row)
+    int pk_idx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col = c16 + 16 * k;
+        const int ks = col & 3, ksub_w = KASC ? (3 - ks) : ks;
+        const int g = col >> 2;
+        pk_idx[k] = (g >> 2) * 256 + (ksub_w * 16 + prow_in_tile) * 4 + (g & 3);
+    }
 
-    const int nb = (n + SB - 1) / SB;
     for (int s = 0; s <= nb; ++s) {
         const int bP = nb - s;      // panel solved in this step (none at s = 0)
         const int bG = nb - 1 - s;  // panel whose residual is produced in this step (none at s = nb)
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        float bpre[16];  // (G) L[(bG+1)*64 + 4g + kslot][colB], g = 0..15: the B operands of part 2
-        [[maybe_unused]] const unsigned long long t_step = SS_T();
+        f32x4v bpre[4];  // (G) packed L block (source panel bG+1, this wave's tile): the B operands of part 2
         if (!roleG) {
             // ---- (P) ---------------------------------------------------------------------------------------
             if (bP <= nb - 1) {
@@ -185,9 +222,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
 #pragma unroll
                     for (int k = 0; k < 4; ++k) wnext[k] = W[(int64_t)prow * n + j0 - SB + c16 + 16 * k];  // full panel
                 }
-                if constexpr (DBG == 5) {
-                    // developer experiment: no panel steps at all (G role alone)
-                } else if (wd == SB) {
+                if (wd == SB) {
                     panel_all<true>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
                 } else {
                     panel_all<false>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
@@ -195,14 +230,13 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int col = c16 + 16 * k;
-                    ErrP[col][prow_in_tile] = (col < wd) ? st.e[k] : 0.0f;
-                    if (col < wd && j0 >= cbase) ErrL[(j0 - cbase + col) * SR + prow_in_tile] = st.e[k];
-                    if (col < wd) {
-                        errt[(int64_t)(j0 + col) * SR + prow_in_tile] = st.e[k];
-                        if (prow_ok) {
-                            Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
-                            if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
-                        }
+                    const float ev = (col < wd) ? st.e[k] : 0.0f;  // the (partial) top panel is zero beyond n
+                    ErrPk[pk_idx[k]] = ev;
+                    if (bP >= pbase) ErrL[(bP - pbase) * 1024 + pk_idx[k]] = ev;
+                    errt[bP * 1024 + pk_idx[k]] = ev;
+                    if (col < wd && prow_ok) {
+                        Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
+                        if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
                     }
                 }
             } else {
@@ -214,10 +248,10 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                 }
             }
         } else if (bG >= 0) {
-            // ---- (G) part 1: columns right of panel bG+1, descending ----------------------------------------
+            // ---- (G) part 1: the panels right of panel bG+1, descending --------------------------------------
             const int j0 = bG * SB;
             const int wd = min(SB, n - j0);
-            const int colB = j0 + 16 * gw + c16;  // < n whenever a product with it is used
+            const int ct = 4 * bG + gw;  // this wave's 16-wide tile of panel bG
             // prefetches for later in this step: the panel's own block of L, its diagonal, the B operands of part 2
             float lpre[(SB * SB) / 256];
 #pragma unroll
@@ -228,114 +262,77 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
             }
             float dpre = 1.0f;
             if (gtid < SB && gtid < wd) dpre = L[(int64_t)(j0 + gtid) * ldl + j0 + gtid];
+            const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0xffffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);
+            // zero records: every load through it is out of range and returns 0
+            const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0, 0x00020000);
+            const int voff = lane * 16;  // this lane's 16 bytes inside each quarter of a packed block
+            if (bG + 1 <= nb - 1) {
+                const uint32_t sb = (uint32_t)((bG + 1) * NT + ct) * 4096u;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int u = j0 + SB + 4 * g + kslot;
-                bpre[g] = (u < n && colB < n) ? L[(int64_t)u * ldl + colB] : 0.0f;
+                for (int j = 0; j < 4; ++j)
+                    bpre[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcL, voff + 1024 * j, (int)sb, 0));
             }
-            {
-                const int gbot = (j0 + 2 * SB) >> 2;
-                if ((n & 3) && (n >> 2) >= gbot) {  // ragged top group: columns >= n contribute nothing
-                    const int u = 4 * (n >> 2) + kslot;
-                    const bool ok = u < n;
-                    const int uu = ok ? u : (n - 1);
-                    const float av = errt[(int64_t)uu * SR + c16];
-                    const float bv = L[(int64_t)uu * ldl + colB];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? av : 0.0f, ok ? bv : 0.0f, acc, 0, 0, 0);
-                }
-                const int gtop = (n >> 2) - 1;     // highest full group
-                const uint32_t laneB = (uint32_t)kslot * (uint32_t)ldl + (uint32_t)colB;
-                const uint32_t laneB4 = 4u * laneB;  // byte offset, < 2^32 (host check on ldl)
-                const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L), 0, 0xffffffff, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);
-                // zero records: every load through it is out of range and returns 0
-                const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L), 0, 0, 0x00020000);
-                // One chain segment: groups ghi, ghi-1, .., glo (descending), A from LDS (columns >= cbase) or from the
-                // global transposed scratch.  Batches of SPF groups, operands loaded two batches ahead into three
-                // rotating register sets; every load is unconditional (indices clamped to the segment) so that the
-                // waits in the steady-state loop count exactly the loads still allowed in flight.
-                auto chain = [&](auto a_in_lds, int ghi, int glo) {
-                    constexpr bool ALDS = decltype(a_in_lds)::value;
-                    const int total = ghi - glo + 1;
-                    if (total <= 0) return;
-                    const int nbat = total / SPF;
-                    const float* __restrict__ Al = ErrL + (int64_t)laneA - (int64_t)cbase * SR;
-                    // buffer loads: (resource, per-lane byte offset in a VGPR, per-group byte offset in an SGPR) -- one
-                    // scalar add and one VMEM instruction per operand, no per-lane 64-bit address arithmetic
-                    const uint32_t bstride_b = (uint32_t)(16 * ldl);  // bytes between the B rows of consecutive groups
-                    // Batches past the end (the loop below always runs whole rounds of three) multiply Err by zeros: their B
-                    // operand comes through rsrcZ (zero records: out-of-range buffer loads return 0), which leaves the accumulator as it is.
-                    auto ld = [&](int bi, float (&aa)[SPF], float (&bb)[SPF]) {
-                        // lowest group of the batch; everything else is a compile-time multiple of a stride above it
-                        const bool real = bi < nbat;
-                        const int glow = ghi - min(bi, nbat - 1) * SPF - (SPF - 1);
-                        uint32_t sB = real ? (uint32_t)glow * bstride_b : 0u;
-                        const uint32_t stepB = real ? bstride_b : 0u;
-                        const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
-                        uint32_t sA = (uint32_t)glow * (uint32_t)(4 * SR * sizeof(float));
-                        const float* __restrict__ Ap = Al + glow * (4 * SR);
+            // One chain segment: source panels phi, phi-1, .., plo (descending), A from LDS (panels >= pbase) or from
+            // the global scratch.  One batch = one source panel = 16 MFMAs; operands are loaded two batches ahead into
+            // three rotating register sets; every load is unconditional and the loop runs whole rounds of three
+            // (batches past the end read B through rsrcZ: zeros leave the accumulator as it is), so that the waits
+            // in the steady state count exactly the loads still allowed in flight.
+            auto chain = [&](auto a_in_lds, int phi, int plo) {
+                constexpr bool ALDS = decltype(a_in_lds)::value;
+                const int nbat = phi - plo + 1;
+                if (nbat <= 0) return;
+                auto ld = [&](int bi, f32x4v (&aa)[4], f32x4v (&bb)[4]) {
+                    const bool real = bi < nbat;
+                    const int ps = phi - min(bi, nbat - 1);  // source panel of the batch
+                    const uint32_t sB = (uint32_t)(ps * NT + ct) * 4096u;
+                    const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
+                    const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * 1024 + lane * 4);
 #pragma unroll
-                        for (int i = 0; i < SPF; ++i) {
-                            if constexpr (DBG == 1) bb[i] = 1.0f + (float)bi;
-                            else bb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)laneB4, (int)sB, 0));
-                            sB += stepB;
-                            if constexpr (DBG == 2) aa[i] = 1.0f + (float)bi;
-                            else if constexpr (ALDS) aa[i] = Ap[i * (4 * SR)];
-                            else aa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcE, (int)(4 * laneA), (int)sA, 0));
-                            sA += 4 * SR * sizeof(float);
-                        }
-                    };
-                    auto mm = [&](const float (&aa)[SPF], const float (&bb)[SPF]) {
-#pragma unroll
-                        for (int i = SPF - 1; i >= 0; --i) {
-                            if constexpr (DBG == 3) acc[0] = fmaf(aa[i], bb[i], acc[0]);
-                            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[i], bb[i], acc, 0, 0, 0);
-                        }
-                    };
-                    if (nbat > 0) {
-                        float a0[SPF], b0[SPF], a1[SPF], b1[SPF], a2[SPF], b2[SPF];
-                        ld(0, a0, b0);
-                        ld(1, a1, b1);
-                        GANQ_PIN();
-                        // One stage = the loads of batch k+2 and the 16 MFMAs of batch k, interleaved one load (two when A
-                        // also comes from memory) per MFMA: a lone wave issues a VMEM instruction every ~16 cycles and a
-                        // dependent MFMA every ~40, so loads issued as a block in front of the MFMAs leave the matrix
-                        // pipe idle for a third of the stage.
-                        auto stage_sched = [&]() {
-#pragma unroll
-                            for (int i = 0; i < SPF / 2; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
-                                __builtin_amdgcn_sched_group_barrier(0x020, ALDS ? 1 : 2, 0);        // VMEM read
-                                if (ALDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // DS read
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x020, ALDS ? 1 : 2, 0);
-                            }
-                        };
-                        for (int bi = 0; bi < nbat; bi += 3) {  // whole rounds, no exits inside: a plain counted loop
-                            ld(bi + 2, a2, b2);
-                            mm(a0, b0);
-                            stage_sched();
-                            GANQ_PIN();
-                            ld(bi + 3, a0, b0);
-                            mm(a1, b1);
-                            stage_sched();
-                            GANQ_PIN();
-                            ld(bi + 4, a1, b1);
-                            mm(a2, b2);
-                            stage_sched();
-                            GANQ_PIN();
-                        }
-                    }
-                    for (int g = ghi - nbat * SPF; g >= glo; --g) {  // fewer than SPF groups left (ragged n only)
-                        const float bv = (L + (int64_t)g * 4 * ldl)[laneB];
-                        const float av = ALDS ? Al[g * (4 * SR)] : (errt + (int64_t)g * (4 * SR))[laneA];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        bb[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * j, (int)sB, 0));
+                        if constexpr (ALDS) aa[j] = Al[j * 64];
+                        else aa[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * j, ps * 4096, 0));
                     }
                 };
-                const int glds = max(gbot, cbase >> 2);  // lowest group whose Err columns live in LDS
-                chain(std::true_type{}, gtop, glds);
-                chain(std::false_type{}, min(gtop, glds - 1), gbot);
-            }
+                auto mm = [&](const f32x4v (&aa)[4], const f32x4v (&bb)[4]) {
+#pragma unroll
+                    for (int g = 15; g >= 0; --g)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g >> 2][g & 3], bb[g >> 2][g & 3], acc, 0, 0, 0);
+                };
+                f32x4v a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
+                ld(0, a0, b0);
+                ld(1, a1, b1);
+                GANQ_PIN();
+                // one stage = the loads of batch k+2 spread between the 16 MFMAs of batch k
+                auto stage_sched = [&]() {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (B)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        if (ALDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (A)
+                        else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (A)
+                    }
+                };
+                for (int bi = 0; bi < nbat; bi += 3) {  // whole rounds, no exits inside: a plain counted loop
+                    ld(bi + 2, a2, b2);
+                    mm(a0, b0);
+                    stage_sched();
+                    GANQ_PIN();
+                    ld(bi + 3, a0, b0);
+                    mm(a1, b1);
+                    stage_sched();
+                    GANQ_PIN();
+                    ld(bi + 4, a1, b1);
+                    mm(a2, b2);
+                    stage_sched();
+                    GANQ_PIN();
+                }
+            };
+            const int plds = max(bG + 2, pbase);  // lowest source panel of this chain whose Err block lives in LDS
+            chain(std::true_type{}, nb - 1, plds);
+            chain(std::false_type{}, min(nb - 1, plds - 1), bG + 2);
 #pragma unroll
             for (int e = 0; e < (SB * SB) / 256; ++e) {
                 const int idx = e * 256 + gtid;
@@ -344,57 +341,73 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
             }
             if (gtid < SB) Dg[bG & 1][gtid] = make_float2(dpre, 1.0f / dpre);
         }
-        SS_ADD(0, t_step, 0);    // P work
-        SS_ADD(1, t_step, 256);  // G part 1
-        __syncthreads();  // panel bP solved (ErrP, ErrT visible); part 1 of panel bG done
-        SS_ADD(2, t_step, 0);    // step up to barrier A
+        __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
         if (roleG && bG >= 0) {
             // ---- (G) part 2: the 64 columns of panel bG+1, descending; then publish R ------------------------
             if (bG + 1 <= nb - 1) {
+                const f32x4v* Ap = reinterpret_cast<const f32x4v*>(ErrPk + lane * 4);
+                f32x4v ap[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ap[j] = Ap[j * 64];
 #pragma unroll
                 for (int g = 15; g >= 0; --g)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ErrP[4 * g + kslot][c16], bpre[g], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[g >> 2][g & 3], bpre[g >> 2][g & 3], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) Rp[bG & 1][rsub * 4 + r][16 * gw + c16] = acc[r];
         }
-        __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrP free
+        __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
     }
 }
 
-}  // namespace ganq
-
-using namespace ganq;
-
-extern "C" size_t ganq_solve_s_workspace_bytes(int64_t m, int64_t n, int V) {
-    (void)V;
-    if (m <= 0 || n <= 0) return 0;
+struct SolveLayout {
+    int nb, NT;
+    size_t errt_bytes, lr_bytes, total;
+};
+static SolveLayout solve_layout(int64_t m, int64_t n) {
+    SolveLayout lo;
+    lo.nb = (int)((n + SB - 1) / SB);
+    lo.NT = 4 * lo.nb;
     const int64_t tiles = (m + SR - 1) / SR;
-    return align_up((size_t)tiles * (size_t)n * SR * sizeof(float), 256);
+    lo.errt_bytes = align_up((size_t)tiles * (size_t)lo.nb * 4096, 256);
+    lo.lr_bytes = align_up((size_t)lo.nb * (size_t)lo.NT * 4096, 256);
+    lo.total = lo.errt_bytes + lo.lr_bytes;
+    return lo;
 }
 
-extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const float* T, int64_t m, int64_t n,
-                            int V, uint8_t* Q_out, float* Err_out, void* workspace, size_t workspace_bytes,
-                            void* stream_) {
-    if (m < 0 || n < 0) return fail(-1, "ganq_solve_s: negative shape m=%lld n=%lld", (long long)m, (long long)n);
-    if (m == 0 || n == 0) return 0;
-    if (V < 2 || V > 16)
-        return fail(-2, "ganq_solve_s: V=%d not supported (bits 2..4 are implemented; bits=8 is not)", V);
-    if (m > INT32_MAX / 2 || n > INT32_MAX / 2) return fail(-1, "ganq_solve_s: shape too large");
-    if (ldl < n) return fail(-1, "ganq_solve_s: ldl=%lld < n=%lld", (long long)ldl, (long long)n);
-    if (ldl * n >= (1ll << 30)) return fail(-1, "ganq_solve_s: L of %lld x %lld floats exceeds the 4 GiB buffer window", (long long)n, (long long)ldl);
-    if (!W || !L || !T || !Q_out) return fail(-3, "ganq_solve_s: null pointer");
-    const size_t need = ganq_solve_s_workspace_bytes(m, n, V);
-    if (!workspace || workspace_bytes < need)
-        return fail(-4, "ganq_solve_s: workspace %zu B < required %zu B", workspace_bytes, need);
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    int rc = ganq_hip_selftest(stream_);
+static int solve_check(const char* who, int64_t m, int64_t n, int V, int64_t ldl) {
+    if (V < 2 || V > 16) return fail(-2, "%s: V=%d not supported (bits 2..4 are implemented; bits=8 is not)", who, V);
+    if (m > INT32_MAX / 2 || n > INT32_MAX / 2) return fail(-1, "%s: shape too large", who);
+    if (ldl < n) return fail(-1, "%s: ldl=%lld < n=%lld", who, (long long)ldl, (long long)n);
+    // packed L: nb * 4 nb blocks of 4 KB behind 32-bit buffer offsets
+    const int64_t nb = (n + SB - 1) / SB;
+    if (nb * 4 * nb * 4096 >= (1ll << 32)) return fail(-1, "%s: n=%lld exceeds the 4 GiB buffer window of the packed L", who, (long long)n);
+    return 0;
+}
+
+// packed copy of L into the workspace (depends on L only: the loop driver does it once per layer)
+int solve_s_pack_l(const float* L, int64_t ldl, int64_t m, int64_t n, void* workspace, hipStream_t stream) {
+    const SolveLayout lo = solve_layout(m, n);
+    float* Lr = reinterpret_cast<float*>(static_cast<char*>(workspace) + lo.errt_bytes);
+    int rc = ganq_hip_selftest(stream);
     if (rc) return rc;
-    const int tiles = (int)((m + SR - 1) / SR);
+    ProfScope prof(KID_T_PREP, stream);  // per-layer preparation, reported with the T-update's
+    hipLaunchKernelGGL(l_pack_kernel, dim3((unsigned)lo.NT, (unsigned)lo.nb), dim3(64), 0, stream, L, ldl, (int)n, lo.NT,
+                       mfma_k_ascending(), Lr);
+    GANQ_LAUNCH_CHECK();
+    return 0;
+}
+
+// the solve proper; the workspace already holds the packed L
+int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, int64_t m, int64_t n, int V, uint8_t* Q_out,
+                   float* Err_out, void* workspace, hipStream_t stream) {
+    const SolveLayout lo = solve_layout(m, n);
     float* errt = static_cast<float*>(workspace);
-    // the top SOLVE_LDS_COLS columns of Err (the ones every later panel re-reads) stay in LDS
-    const int cbase = (int)std::max<int64_t>(0, (n - SOLVE_LDS_COLS + SB - 1) / SB * SB);
-    const size_t smem = (size_t)(n - cbase) * SR * sizeof(float);
+    const float* Lr = reinterpret_cast<const float*>(static_cast<char*>(workspace) + lo.errt_bytes);
+    const int tiles = (int)((m + SR - 1) / SR);
+    // the Err blocks of the top SOLVE_LDS_PANELS panels (the ones every later panel re-reads) stay in LDS
+    const int pbase = std::max(0, lo.nb - SOLVE_LDS_PANELS);
+    const size_t smem = (size_t)(lo.nb - pbase) * 4096;
     static size_t attr_smem = 0;
     if (smem > attr_smem) {
         GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true>),
@@ -404,40 +417,40 @@ extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const f
         attr_smem = smem;
     }
     ProfScope prof(KID_SOLVE_S, stream);
-#ifdef GANQ_SOLVE_DEBUG
-    if (const char* dm = getenv("GANQ_SOLVE_DBG")) {
-        const int d = atoi(dm);
-#define GANQ_DBG_LAUNCH(D) hipLaunchKernelGGL((solve_s_kernel<true, D>), dim3(tiles), dim3(512), smem, stream, W, L, ldl, T, (int)m, (int)n, V, Q_out, Err_out, errt, cbase)
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        if (d == 1) GANQ_DBG_LAUNCH(1);
-        else if (d == 2) GANQ_DBG_LAUNCH(2);
-        else if (d == 3) GANQ_DBG_LAUNCH(3);
-        else if (d == 5) GANQ_DBG_LAUNCH(5);
-        else GANQ_DBG_LAUNCH(0);
-        GANQ_LAUNCH_CHECK();
-        return 0;
-    }
-#endif
     if (mfma_k_ascending()) {
-        hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, T, (int)m, (int)n, V,
-                           Q_out, Err_out, errt, cbase);
+        hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
+                           V, Q_out, Err_out, errt, pbase);
     } else {
-        hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, T, (int)m, (int)n, V,
-                           Q_out, Err_out, errt, cbase);
+        hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
+                           V, Q_out, Err_out, errt, pbase);
     }
     GANQ_LAUNCH_CHECK();
     return 0;
 }
 
-#ifdef GANQ_SOLVE_DEBUG
-extern "C" int ganq_debug_solve_cycles(unsigned long long* out8) {
-    GANQ_HIP_CHECK(hipDeviceSynchronize());
-    GANQ_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ganq::ss_dbg), 8 * sizeof(unsigned long long)));
-    unsigned long long z[8] = {0};
-    GANQ_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ganq::ss_dbg), z, sizeof(z)));
-    return 0;
+}  // namespace ganq
+
+using namespace ganq;
+
+extern "C" size_t ganq_solve_s_workspace_bytes(int64_t m, int64_t n, int V) {
+    (void)V;
+    if (m <= 0 || n <= 0) return 0;
+    return solve_layout(m, n).total;
 }
-#endif
+
+extern "C" int ganq_solve_s(const float* W, const float* L, int64_t ldl, const float* T, int64_t m, int64_t n,
+                            int V, uint8_t* Q_out, float* Err_out, void* workspace, size_t workspace_bytes,
+                            void* stream_) {
+    if (m < 0 || n < 0) return fail(-1, "ganq_solve_s: negative shape m=%lld n=%lld", (long long)m, (long long)n);
+    if (m == 0 || n == 0) return 0;
+    int rc = solve_check("ganq_solve_s", m, n, V, ldl);
+    if (rc) return rc;
+    if (!W || !L || !T || !Q_out) return fail(-3, "ganq_solve_s: null pointer");
+    const size_t need = ganq_solve_s_workspace_bytes(m, n, V);
+    if (!workspace || workspace_bytes < need)
+        return fail(-4, "ganq_solve_s: workspace %zu B < required %zu B", workspace_bytes, need);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    rc = solve_s_pack_l(L, ldl, m, n, workspace, stream);
+    if (rc) return rc;
+    return solve_s_launch(W, L, ldl, T, m, n, V, Q_out, Err_out, workspace, stream);
+}
