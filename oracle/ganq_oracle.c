@@ -294,12 +294,14 @@ int ganq_oracle_matmul(const float* A, const float* B, int64_t m, int64_t k, int
  * ------------------------------------------------------------------------------------------ */
 int ganq_oracle_quad_loss(const float* W, const float* H, const float* T, const uint8_t* Q, int64_t m, int64_t n,
                           int V, double* loss_out, double* row_loss_out) {
-    double total = 0.0;
+    /* per-row terms first, then one sum in row order: the total does not depend on the OpenMP schedule (two
+     * iterations with the same indices must give the same distance bit for bit, best-of-K compares them) */
+    double* rows = (double*)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
 #pragma omp parallel
     {
         float* e = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
         double* acc = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-#pragma omp for schedule(dynamic, 4) reduction(+ : total)
+#pragma omp for schedule(dynamic, 4)
         for (int64_t i = 0; i < m; ++i) {
             for (int64_t u = 0; u < n; ++u) e[u] = W[i * n + u] - T[i * V + Q[i * n + u]];
             for (int64_t v = 0; v < n; ++v) acc[v] = 0.0;
@@ -310,12 +312,17 @@ int ganq_oracle_quad_loss(const float* W, const float* H, const float* T, const 
             }
             double r = 0.0;
             for (int64_t v = 0; v < n; ++v) r += acc[v] * (double)e[v];
-            if (row_loss_out) row_loss_out[i] = r;
-            total += r;
+            rows[i] = r;
         }
         free(e);
         free(acc);
     }
+    double total = 0.0;
+    for (int64_t i = 0; i < m; ++i) {
+        if (row_loss_out) row_loss_out[i] = rows[i];
+        total += rows[i];
+    }
+    free(rows);
     *loss_out = total;
     return 0;
 }
