@@ -80,3 +80,58 @@ def test_run_layer_full_size_is_deterministic_and_improves(layer):
     d = a[2].cpu().numpy()
     assert np.all(np.isfinite(d)) and d[-1] < d[0]
     assert int(a[3]) == int(np.argmin(d))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Llama-class in_features (down_proj of a 7B model: n = 11008 -- not a power of two, 172 panels): every stage against
+# the oracle on a handful of rows
+@pytest.fixture(scope="module")
+def wide_layer():
+    from ganq_amd import _lib
+
+    m, n, V = 24, 11008, 16
+    g = torch.Generator(device="cuda").manual_seed(1)
+    W = (0.02 * torch.randn(m, n, device="cuda", generator=g)).half().float()
+    X = torch.randn(2 * n, n, device="cuda", generator=g) * (0.1 + torch.rand(n, device="cuda", generator=g))
+    H = (2.0 / X.shape[0]) * (X.T @ X)
+    del X
+    H += 0.01 * H.diag().mean() * torch.eye(n, device="cuda")
+    H = 0.5 * (H + H.T)
+    off = (H.abs().sum(1) - 2 * H.diag()).clamp(min=1e-8)
+    L = _lib.cholesky(H + torch.diag(off))
+    T0 = torch.quantile(W, (torch.arange(V, device="cuda") + 0.5) / V, dim=1).T.contiguous()
+    return dict(W=W, H=H, L=L, T0=T0, V=V, m=m, n=n)
+
+
+def test_wide_layer_solve_and_update_vs_oracle(wide_layer):
+    from ganq_amd import _lib
+    from oracle import c_oracle
+
+    d = wide_layer
+    Wn, Hn, Ln, Tn = (d[k].cpu().numpy() for k in ("W", "H", "L", "T0"))
+    Q = _lib.solve_s(d["W"], d["L"], d["T0"])
+    Qo = c_oracle.solve_s(Wn, Ln, Tn)
+    assert np.array_equal(Q.cpu().numpy(), Qo)
+    WH = _lib.matmul_f32(d["W"], d["H"])
+    T1 = _lib.update_t(WH, d["H"], Q, d["V"])
+    T1o = c_oracle.update_t(WH.cpu().numpy(), Hn, Qo, d["V"])
+    assert rel_fro(T1.cpu().numpy(), T1o) < 1e-5
+
+
+def test_wide_layer_kmeans_and_loop(wide_layer):
+    from ganq_amd import _lib
+    from oracle import c_oracle
+
+    d = wide_layer
+    g = torch.Generator(device="cuda").manual_seed(2)
+    cw = (torch.rand(d["n"], device="cuda", generator=g, dtype=torch.float64) + 0.5) ** 4
+    rows = slice(0, 3)
+    T0 = _lib.kmeans_init(d["W"][rows], cw, d["V"])  # windowed kernel (n > 4.7 k)
+    T0o = c_oracle.kmeans_init(d["W"][rows].cpu().numpy(), cw.cpu().numpy(), d["V"])
+    assert rel_fro(T0.cpu().numpy(), T0o) < 1e-6
+    # the whole loop, incremental bucket sums included, is deterministic and improves the loss
+    a = _lib.run_layer(d["W"], d["H"], d["L"], d["T0"], 3)
+    b = _lib.run_layer(d["W"], d["H"], d["L"], d["T0"], 3)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    dist = a[2].cpu().numpy()
+    assert dist[-1] < dist[0]
