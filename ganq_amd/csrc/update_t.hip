@@ -100,18 +100,20 @@ __global__ __launch_bounds__(256) void code_masks_kernel(const uint8_t* __restri
                                                         const long long* __restrict__ changed, long long thr) {
     if (changed && *changed <= thr) return;
     const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (int64_t)m * ng) return;
-    const int row = (int)(item / ng), g = (int)(item % ng);
-    const int u = 64 * g + lane;
-    const uint32_t q = u < n ? Q[(int64_t)row * n + u] : 255u;
-    unsigned long long mine = 0;
+    // grid-stride over (row, 64-column group) items: the grid stays small, so the gated-off launches of the
+    // incremental iterations cost a few microseconds instead of 15
+    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < (int64_t)m * ng; item += (int64_t)gridDim.x * 4) {
+        const int row = (int)(item / ng), g = (int)(item % ng);
+        const int u = 64 * g + lane;
+        const uint32_t q = u < n ? Q[(int64_t)row * n + u] : 255u;
+        unsigned long long mine = 0;
 #pragma unroll
-    for (uint32_t a = 0; a < 16; ++a) {
-        const unsigned long long mk = __ballot(q == a);
-        if ((uint32_t)lane == a) mine = mk;
+        for (uint32_t a = 0; a < 16; ++a) {
+            const unsigned long long mk = __ballot(q == a);
+            if ((uint32_t)lane == a) mine = mk;
+        }
+        if (lane < 16) bits[item * 16 + lane] = mine;
     }
-    if (lane < 16) bits[item * 16 + lane] = mine;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -926,7 +928,7 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
     {
         ProfScope prof(KID_SORT_CODES, stream);
         const int64_t items = m * lo.ng;
-        hipLaunchKernelGGL(code_masks_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, Q, (int)m, (int)n,
+        hipLaunchKernelGGL(code_masks_kernel, dim3((unsigned)std::min<int64_t>((items + 3) / 4, 4096)), dim3(256), 0, stream, Q, (int)m, (int)n,
                            (int)lo.ng, bits, gate, thr);
     }
     GANQ_LAUNCH_CHECK();
