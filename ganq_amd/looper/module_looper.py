@@ -28,7 +28,11 @@ def find_modules(layer: nn.Module, names: Sequence[str]) -> Dict[str, nn.Module]
 
 class ModuleLooper:
     def __init__(self, processor, layers: Sequence[nn.Module], layer_modules: List[List[str]],
-                 layers_prefix: str = "model.layers"):
+                 layers_prefix: str = "model.layers", share_group_hessian: bool = True):
+        # share_group_hessian: the modules of one group ([q,k,v], [gate,up]) receive the same inputs, so the first
+        # one accumulates the Hessian and runs the prologue (permutation, factor, damping) for all of them; the
+        # reference does both once per module.  Same numbers, less work.
+        self.share_group_hessian = share_group_hessian
         self.processor = processor
         self.layers = layers
         self.layer_modules = layer_modules
@@ -54,10 +58,19 @@ class ModuleLooper:
                                        for n, nm in named.items()}, dist.world)
                 mine = [n for n in named if owners[n] == dist.rank]
                 handles = []
+                leader = None  # the modules of a group see the same inputs: one Hessian / prologue for all of them
                 for n in mine:
                     self.processor.preprocess(named[n], buffered_fwd=False)
-                    if not self.processor.is_skipped(named[n]):
-                        handles.append(mods[n].register_forward_hook(self.processor.preprocess_fwd_hook(n)))
+                    if self.processor.is_skipped(named[n]):
+                        continue
+                    task = self.processor.tasks[n]
+                    if (self.share_group_hessian and leader is not None
+                            and self.processor.tasks[leader].columns == task.columns):
+                        task.follow(self.processor.tasks[leader])
+                        continue
+                    if leader is None:
+                        leader = n
+                    handles.append(mods[n].register_forward_hook(self.processor.preprocess_fwd_hook(n)))
                 for x, kw in zip(layer_inputs, layer_kwargs):
                     fwd(layer, x, kw)
                 for h in handles:
@@ -65,7 +78,11 @@ class ModuleLooper:
                 for n in mine:
                     if self.processor.is_skipped(named[n]):
                         continue
-                    if self.processor.tasks[n].fwd_counter == 0:  # module never hit (module_looper.py:335-343)
+                    task = self.processor.tasks[n]
+                    lead = getattr(task, "_group_leader", None)
+                    if lead is not None:
+                        task.fwd_counter, task.nsamples = lead.fwd_counter, lead.nsamples
+                    if task.fwd_counter == 0:  # module never hit (module_looper.py:335-343)
                         raise RuntimeError(f"module {named[n].full_name} saw no calibration activations")
                     self.processor.process(named[n])
                     if progress:

@@ -111,7 +111,22 @@ class GPTQ:
                                   "use ganq_amd.quantization.GANQ")
 
     # ---- gptq.py:238-375 ---------------------------------------------------------------------------------
-    @torch.inference_mode()
+    # ---- not in the reference: modules of one looper group (q/k/v, gate/up) see the same inputs, hence the same
+    #      Hessian, permutation, factor and damping; the reference recomputes all of it per module --------------------
+    def follow(self, leader: "GPTQ"):
+        """Take the Hessian statistics and the prologue from `leader` (same in_features, same calibration inputs,
+        quantized before this module) instead of accumulating and factoring an identical copy."""
+        if leader.columns != self.columns:
+            raise ValueError("follow(): the modules of a group must have the same in_features")
+        self._group_leader = leader
+        self._leader_prologue = None  # filled in by the leader's quantize()
+        leader._followers = getattr(leader, "_followers", []) + [self]
+
+    def _prologue_key(self):
+        c = self.qcfg
+        return (self.columns, c.act_sort, c.l_damp_style, c.damp_percent, c.damp_auto_increment, c.dead,
+                getattr(c, "ganq_prologue", "torch"), self._needs_only_hinv_diag())
+
     def _needs_only_hinv_diag(self) -> bool:
         """True when the quantization loop reads nothing of Hinv but its diagonal (GANQ does; see ganq.py)."""
         return False
@@ -121,6 +136,7 @@ class GPTQ:
         from .. import _lib
         return _lib.cholesky(H)
 
+    @torch.inference_mode()
     def quantize(self, blocksize=128):
         start = time.time()
         for inp in self.fwd_inputs_buffered_data:
@@ -132,65 +148,87 @@ class GPTQ:
         else:
             W = self.module_copy
             self.module_copy = None
-        if not hasattr(self, "H"):
+        if not hasattr(self, "H") and getattr(self, "_leader_prologue", None) is None:
             raise RuntimeError("quantize() called before any add_batch(): no calibration activations were seen")
 
         self.quantizer.find_params(W, weight=True)
 
-        H = self.H
-        del self.H
-        dead = torch.diag(H) == 0
-        H[dead, dead] = 1
-        if self.qcfg.dead == "zero":
-            W[:, dead] = 0
-        elif self.qcfg.dead == "mean":
-            W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
+        cached = getattr(self, "_leader_prologue", None)
+        if cached is not None and cached["key"] == self._prologue_key():
+            dead, perm, invperm = cached["dead"], cached["perm"], cached["invperm"]
+            if self.qcfg.dead == "zero":
+                W[:, dead] = 0
+            elif self.qcfg.dead == "mean":
+                W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
+            if perm is not None:
+                W = W[:, perm].contiguous()
+            self.Xxt, self.L, self.Xxt_damped = cached["Xxt"], cached["L"], cached["Xxt_damped"]
+            Hinv, damp_percent = cached["Hinv"], cached["damp_percent"]
+            self.nsamples = cached["nsamples"]
         else:
-            assert False, f"Unknown dead mode: {self.qcfg.dead}"
+            if not hasattr(self, "H"):
+                raise RuntimeError("quantize(): this module follows a leader that has not been quantized (yet)")
+            H = self.H
+            del self.H
+            dead = torch.diag(H) == 0
+            H[dead, dead] = 1
+            if self.qcfg.dead == "zero":
+                W[:, dead] = 0
+            elif self.qcfg.dead == "mean":
+                W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
+            else:
+                assert False, f"Unknown dead mode: {self.qcfg.dead}"
 
-        perm = None
-        invperm = None
-        if self.qcfg.act_sort != "none":
-            assert self.qcfg.act_sort in ["asc", "desc"]
-            perm = torch.argsort(torch.diag(H), descending=self.qcfg.act_sort == "desc")
-            W = W[:, perm].contiguous()
-            H = H[perm][:, perm].contiguous()
-            invperm = torch.argsort(perm)
+            perm = None
+            invperm = None
+            if self.qcfg.act_sort != "none":
+                assert self.qcfg.act_sort in ["asc", "desc"]
+                perm = torch.argsort(torch.diag(H), descending=self.qcfg.act_sort == "desc")
+                W = W[:, perm].contiguous()
+                H = H[perm][:, perm].contiguous()
+                invperm = torch.argsort(perm)
 
-        self.Xxt = H.clone()  # undamped
-        # the GANQ loop only reads diag(Hinv), which one factorisation of the index-reversed matrix gives (config.py)
-        native = (getattr(self.qcfg, "ganq_prologue", "torch") == "hip" and self._needs_only_hinv_diag() and H.is_cuda)
-        chol = self._hip_cholesky if native else torch.linalg.cholesky
-        if self.qcfg.l_damp_style == "ganq":
-            offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
-            self.L = chol(H + torch.diag(offset))
+            self.Xxt = H.clone()  # undamped
+            # the GANQ loop only reads diag(Hinv), which one factorisation of the index-reversed matrix gives (config.py)
+            native = (getattr(self.qcfg, "ganq_prologue", "torch") == "hip" and self._needs_only_hinv_diag() and H.is_cuda)
+            chol = self._hip_cholesky if native else torch.linalg.cholesky
+            if self.qcfg.l_damp_style == "ganq":
+                offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
+                self.L = chol(H + torch.diag(offset))
 
-        damp_percent = self.qcfg.damp_percent
-        Hinv = None
-        while 1 > damp_percent > 0:
-            try:
-                damp = damp_percent * torch.mean(torch.diag(H))
-                diag = torch.arange(self.columns, device=self.device)
-                H[diag, diag] += damp
-                self.Xxt_damped = H.clone()
-                if native:
-                    if self.qcfg.l_damp_style == "gptq":
-                        self.L = chol(H)
-                    Lr = chol(torch.flip(H, dims=(0, 1)))
-                    Hinv = torch.flip(1.0 / torch.diagonal(Lr), dims=(0,)).contiguous()  # 1-D: the diagonal only
-                else:
-                    L = torch.linalg.cholesky(H)
-                    if self.qcfg.l_damp_style == "gptq":
-                        self.L = L.clone()
-                    Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
-                break
-            except torch._C._LinAlgError as e:
-                if self.qcfg.damp_auto_increment != 0:
-                    damp_percent += self.qcfg.damp_auto_increment
-                else:
-                    raise e
-        if not (0 < damp_percent < 1):
-            raise ValueError(f"Quantization: `damp_percent` must between 0 and 1. current is {damp_percent}")
+            damp_percent = self.qcfg.damp_percent
+            Hinv = None
+            while 1 > damp_percent > 0:
+                try:
+                    damp = damp_percent * torch.mean(torch.diag(H))
+                    diag = torch.arange(self.columns, device=self.device)
+                    H[diag, diag] += damp
+                    self.Xxt_damped = H.clone()
+                    if native:
+                        if self.qcfg.l_damp_style == "gptq":
+                            self.L = chol(H)
+                        Lr = chol(torch.flip(H, dims=(0, 1)))
+                        Hinv = torch.flip(1.0 / torch.diagonal(Lr), dims=(0,)).contiguous()  # 1-D: the diagonal only
+                    else:
+                        L = torch.linalg.cholesky(H)
+                        if self.qcfg.l_damp_style == "gptq":
+                            self.L = L.clone()
+                        Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
+                    break
+                except torch._C._LinAlgError as e:
+                    if self.qcfg.damp_auto_increment != 0:
+                        damp_percent += self.qcfg.damp_auto_increment
+                    else:
+                        raise e
+            if not (0 < damp_percent < 1):
+                raise ValueError(f"Quantization: `damp_percent` must between 0 and 1. current is {damp_percent}")
+            followers = getattr(self, "_followers", [])
+            if followers:
+                shared = {"key": self._prologue_key(), "dead": dead, "perm": perm, "invperm": invperm, "Xxt": self.Xxt,
+                          "L": self.L, "Xxt_damped": self.Xxt_damped, "Hinv": Hinv, "damp_percent": damp_percent,
+                          "nsamples": self.nsamples}
+                for f in followers:
+                    f._leader_prologue = shared
 
         Q, Losses, scale, zero = self._perform_quantization_loop(W, Hinv, blocksize, perm, invperm)
 

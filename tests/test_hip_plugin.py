@@ -143,6 +143,31 @@ def test_processor_looper_and_quantlinear():
     assert err < 0.1, float(err)
 
 
+@torch.no_grad()
+def test_looper_shared_group_hessian_is_identical():
+    # q/k/v see the same inputs: one Hessian + prologue for the group must give exactly what three separate ones give
+    from ganq_amd.looper.gptq_processor import GPTQProcessor
+    from ganq_amd.looper.module_looper import ModuleLooper
+    from ganq_amd.quantization import QuantizeConfig
+
+    res = []
+    for share in (False, True):
+        torch.manual_seed(0)
+        model = nn.Module()
+        model.layers = nn.ModuleList([ToyLayer(64, 128)])
+        model = model.half().cuda()
+        xs = [torch.randn(2, 48, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5 + i)).half()
+              for i in range(3)]
+        qcfg = QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=3)
+        proc = GPTQProcessor(qcfg)
+        ModuleLooper(proc, model.layers, [["q_proj", "k_proj", "v_proj"], ["out_proj"], ["fc1"], ["fc2"]],
+                     layers_prefix="layers", share_group_hessian=share).loop(xs)
+        res.append({k: (v["ganq_q"].clone(), v["ganq_lut"].clone()) for k, v in proc.results().items()})
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 6
+    for k in res[0]:
+        assert torch.equal(res[0][k][0], res[1][k][0]) and torch.equal(res[0][k][1], res[1][k][1]), k
+
+
 @pytest.mark.parametrize("bits,rows", [(4, 1), (4, 40), (3, 7), (2, 16)])
 def test_quantlinear_pack_forward_and_state_dict(bits, rows):
     from ganq_amd.nn_modules.qlinear.ganq_hip import GanqHipQuantLinear
