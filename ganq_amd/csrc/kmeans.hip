@@ -130,6 +130,120 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
     }
 }
 
+// Balanced variant for the levels with many nodes (resident kernel).  A node's candidate range is short on average
+// (~3) but heavy-tailed: wherever the argmin jumps, one node of a wave has tens to hundreds of candidates and its
+// 63 neighbours wait.  Here every node takes its first KB_CAP candidates itself; what is left of the long ranges is
+// queued (one 64-bit atomic hands out the queue slot and the offset of the range in a flat item space) and then
+// spread evenly over all 1024 threads.  The per-node minimum over the spread items is an LDS atomic min on the cost
+// bits (non-negative doubles order like their bit patterns), the leftmost-argmin tie-break a second atomic min on j
+// among the items that reached that cost -- the same (cost, j) order as a sequential scan.
+constexpr int KB_CAP = 8;      // candidates a node evaluates itself (4096x4096, V=16: 1 -> 27.4, 2 -> 18.3, 4 -> 17.5, 8 -> 17.2 ms)
+constexpr int KB_QMAX = 512;   // queued ranges per level (more: finished in place)
+constexpr int KB_SLOTS = 8;    // spread items per thread (covers n + nodes <= 8192 items)
+struct KmQueue {               // LDS scratch of the balanced levels
+    unsigned long long ctr;                 // (entries << 32) | items
+    unsigned long long cost[KB_QMAX];       // min cost bits over the spread items
+    unsigned long long seedc[KB_QMAX];      // best of the node's own first KB_CAP candidates
+    unsigned int off[KB_QMAX];              // first flat item of the range
+    unsigned int j[KB_QMAX];                // leftmost argmin among the spread items
+    unsigned int seedj[KB_QMAX];
+    unsigned short t[KB_QMAX], jstart[KB_QMAX], cnt[KB_QMAX];
+};
+
+__device__ __forceinline__ void km_level_balanced(const double* cw, const double* cwx, const double* cwxx, const double* dprev,
+                                                  uint16_t* acur, double* dcur, int* ag, int cnt, int hs, int n, KmQueue* q) {
+    const int tid = threadIdx.x;
+    // ---- A: own candidates, queue the rest ----
+    for (int t = tid; t < cnt; t += KL_THREADS) {
+        const int i = hs - 1 + t * 2 * hs;
+        const int lo = (i - hs >= 0) ? (int)acur[i - hs] : 0;
+        const int right = (i + hs < n) ? (i + hs) : (n - 1);
+        const int hi = max(lo, min(i, (int)acur[right]));
+        const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
+        double bc = INFINITY;
+        int bj = 0x7fffffff;
+        const int own_hi = min(hi, lo + KB_CAP - 1);
+        for (int j = lo; j <= own_hi; ++j) km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+        const int rest = hi - own_hi;
+        bool queued = false;
+        if (rest > 0) {
+            const unsigned long long e = atomicAdd(&q->ctr, (1ull << 32) | (unsigned long long)rest);
+            const unsigned int idx = (unsigned int)(e >> 32);
+            if (idx < (unsigned int)KB_QMAX) {
+                q->t[idx] = (unsigned short)t;
+                q->jstart[idx] = (unsigned short)(own_hi + 1);
+                q->cnt[idx] = (unsigned short)min(rest, 65535);
+                q->off[idx] = (unsigned int)e;
+                q->cost[idx] = 0x7ff0000000000000ull;  // +inf
+                q->j[idx] = 0xffffffffu;
+                q->seedc[idx] = (unsigned long long)__double_as_longlong(bc);
+                q->seedj[idx] = (unsigned int)bj;
+                queued = true;
+            } else {
+                for (int j = own_hi + 1; j <= hi; ++j)
+                    km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+            }
+        }
+        if (!queued) {
+            dcur[i] = bc;
+            ag[i] = bj;
+            acur[i] = (uint16_t)bj;
+        }
+    }
+    __syncthreads();
+    // ---- B: the queued candidates as one flat item space, KL_THREADS items at a time ----
+    const unsigned long long ctr = q->ctr;
+    const int nq = min((int)(ctr >> 32), KB_QMAX);
+    const unsigned int total = (unsigned int)ctr;
+    unsigned long long sc[KB_SLOTS];
+    int se[KB_SLOTS], sj[KB_SLOTS];
+#pragma unroll
+    for (int r = 0; r < KB_SLOTS; ++r) {
+        se[r] = -1;
+        const unsigned int w = (unsigned int)tid + (unsigned int)r * KL_THREADS;
+        if (w < total && nq > 0) {
+            int lo_e = 0, hi_e = nq - 1;  // largest entry with off <= w (offsets ascend with the entry index)
+            while (lo_e < hi_e) {
+                const int mid = (lo_e + hi_e + 1) >> 1;
+                if (q->off[mid] <= w) lo_e = mid; else hi_e = mid - 1;
+            }
+            const unsigned int d = w - q->off[lo_e];
+            if (q->off[lo_e] <= w && d < (unsigned int)q->cnt[lo_e]) {
+                const int t = q->t[lo_e];
+                const int i = hs - 1 + t * 2 * hs;
+                const int j = (int)q->jstart[lo_e] + (int)d;
+                const double c = dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], cw[i + 1], cwx[i + 1], cwxx[i + 1]);
+                const unsigned long long cb = (unsigned long long)__double_as_longlong(c);
+                atomicMin(&q->cost[lo_e], cb);
+                sc[r] = cb;
+                se[r] = lo_e;
+                sj[r] = j;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- C: leftmost item among those that reached the minimum ----
+#pragma unroll
+    for (int r = 0; r < KB_SLOTS; ++r)
+        if (se[r] >= 0 && sc[r] == q->cost[se[r]]) atomicMin(&q->j[se[r]], (unsigned int)sj[r]);
+    __syncthreads();
+    // ---- D: a node's own candidates lie left of its queued ones: they win ties ----
+    for (int e = tid; e < nq; e += KL_THREADS) {
+        const int i = hs - 1 + (int)q->t[e] * 2 * hs;
+        unsigned long long cb = q->seedc[e];
+        unsigned int bj = q->seedj[e];
+        if (q->cost[e] < cb) {
+            cb = q->cost[e];
+            bj = q->j[e];
+        }
+        dcur[i] = __longlong_as_double((long long)cb);
+        ag[i] = (int)bj;
+        acur[i] = (uint16_t)bj;
+    }
+    if (tid == 0) q->ctr = 0;
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __restrict__ W, const double* __restrict__ col_weight,
                                                                 int m, int n, int V, int P, float* __restrict__ T0,
                                                                 char* __restrict__ ws, size_t ws_stride) {
@@ -140,6 +254,7 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
     double* cwxx = cwx + n1;
     double* dprev = cwxx + n1;
     uint16_t* acur = reinterpret_cast<uint16_t*>(dprev + n1);  // [n] argmins of the layer being solved
+    KmQueue* kq = reinterpret_cast<KmQueue*>(km_smem + align_up(4 * (size_t)n1 * sizeof(double) + (size_t)n * sizeof(uint16_t), 16));
     uint64_t* keys = reinterpret_cast<uint64_t*>(km_smem);     // [P] during the sort only (8P <= 16(n+1): over cw, cwx)
     double* ctot = dprev;                                       // [3][nchunk] during the prefix sums only
     __shared__ double red_c[KL_THREADS / 64];
@@ -241,6 +356,7 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
         __syncthreads();
 
         KM_STAMP(1);
+        if (tid == 0) kq->ctr = 0;
         // ---- 3. DP ----------------------------------------------------------------------------------------
         for (int i = tid; i < n; i += KL_THREADS) {
             dcur[i] = km_cost4(cw[0], cwx[0], cwxx[0], cw[i + 1], cwx[i + 1], cwxx[i + 1]);
@@ -285,7 +401,9 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
                 int G = 1;
                 while (G < KL_THREADS && G * 2 * cnt <= KL_THREADS) G <<= 1;
                 const int lg = tid & (G - 1);
-                if (G <= 64) {
+                if (cnt >= 128 && cnt <= KB_SLOTS * KL_THREADS - n) {
+                    km_level_balanced(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
+                } else if (G <= 64) {
                     km_level_nodes(cw, cwx, cwxx, dprev, 0, cw, cwx, cwxx, acur, dcur, ag, 0, cnt - 1, hs, n, G);
                     __syncthreads();
                 } else {
@@ -624,7 +742,7 @@ static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
     while (p.P < n) p.P <<= 1;
     p.Wcap = 0;
     const size_t acur_bytes = align_up((size_t)n * sizeof(uint16_t), 16);
-    const size_t lds_bytes = 4 * (size_t)(n + 1) * sizeof(double) + acur_bytes;
+    const size_t lds_bytes = align_up(4 * (size_t)(n + 1) * sizeof(double) + (size_t)n * sizeof(uint16_t), 16) + sizeof(KmQueue);
     p.lds = lds_bytes <= KM_LDS_BUDGET;
     const char* force = getenv("GANQ_KMEANS_WCAP");  // testing: force the windowed kernel with a small window
     const int forced = force ? atoi(force) : 0;
