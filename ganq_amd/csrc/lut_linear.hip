@@ -37,7 +37,8 @@ __device__ __forceinline__ uint32_t extract(const uint32_t (&w)[BITS], int j) {
 
 constexpr int LW = 4;          // waves per workgroup
 constexpr int LUT_MAX_M = 64;  // rows of x one call takes (4 row tiles of 16)
-constexpr int LUT_FB = 32 * LW;  // output features per workgroup
+constexpr int LUT_FB = 32 * LW;  // output features per workgroup (split-K-through-memory variant)
+constexpr int LWK = 16;          // waves per workgroup of the in-workgroup split variant
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -62,8 +63,12 @@ __device__ __forceinline__ uint32_t lds_pair(uint32_t addr_lo, uint32_t addr_hi)
 //   per-lane dynamic lookup is bank-conflict free.
 //   Split-K: each workgroup stores its partial tile, takes a ticket on the feature block's counter, and the last
 //   one to arrive sums the partials in ks order (deterministic), adds the bias and writes y; it leaves the counter 0.
-template <int BITS, int RT, bool BF16>
-__global__ __launch_bounds__(LW * 64) void lut_mfma_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+// NW waves per workgroup.  INWG = false: every wave owns its own 32 features, blockIdx.y splits in_features and the
+// partial tiles meet in memory (ticket).  INWG = true: the NW waves share ONE set of 32 features and split
+// in_features among themselves; the partial tiles meet in LDS -- no second memory round trip, which at decode sizes
+// is what the kernel's time is made of.
+template <int BITS, int RT, bool BF16, int NW, bool INWG>
+__global__ __launch_bounds__(NW * 64) void lut_mfma_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                           const uint16_t* __restrict__ lut, const uint16_t* __restrict__ bias,
                                                           int M, int m, int n, int kb_per_wg, int KS,
                                                           float* __restrict__ partial, int* __restrict__ counters,
@@ -71,15 +76,17 @@ __global__ __launch_bounds__(LW * 64) void lut_mfma_kernel(const uint16_t* __res
     constexpr int V = 1 << BITS;
     constexpr int KC = 4;  // groups in flight per wave (loads issued one chunk ahead)
     constexpr bool STRADDLE = (8 * BITS) % 16 != 0;  // 3-bit: a lane's 24 bits can span two words
-    __shared__ __attribute__((aligned(4096))) uint32_t tbl[LW][2][V][64];  // 4 KB alignment: see the v_perm addressing
+    __shared__ __attribute__((aligned(4096))) uint32_t tbl[INWG ? 1 : NW][2][V][64];  // 4 KB alignment: see the v_perm addressing
     __shared__ int s_ticket;
+    __shared__ float red[INWG ? NW - 1 : 1][2][RT][4][64];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, q = lane >> 4;
-    const int o0 = blockIdx.x * LUT_FB + 32 * wv, ks = blockIdx.y;
+    const int o0 = INWG ? blockIdx.x * 32 : blockIdx.x * (32 * NW) + 32 * wv, ks = blockIdx.y;
     const int nkb = n >> 5;
-    const int kb_begin = ks * kb_per_wg;
-    const int kb_end = min(nkb, kb_begin + kb_per_wg);  // kb_begin < nkb by construction of the grid
+    // INWG: kb_per_wg is the per-WAVE share of the groups; a wave past the end simply has an empty range
+    const int kb_begin = INWG ? min(nkb, wv * kb_per_wg) : ks * kb_per_wg;
+    const int kb_end = min(nkb, kb_begin + kb_per_wg);
     const int off = 8 * BITS * q, wi = off >> 5, sh = off & 31;
     const int wi2 = STRADDLE ? min(wi + 1, BITS - 1) : wi;
     const int oc0 = min(o0 + col, m - 1), oc1 = min(o0 + 16 + col, m - 1);
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(LW * 64) void lut_mfma_kernel(const uint16_t* __res
         for (int c = 0; c < KC; ++c) {
             const int kb = kb0 + c;
             const bool ok = kb < kb_end;
-            const int kbc = ok ? kb : kb_begin;
+            const int kbc = ok ? kb : min(kb_begin, nkb - 1);
             const int64_t row = (int64_t)(kbc * BITS + wi) * m, row2 = (int64_t)(kbc * BITS + wi2) * m;
             wl[buf][c][0] = qw[row + oc0];
             wl[buf][c][1] = qw[row + oc1];
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(LW * 64) void lut_mfma_kernel(const uint16_t* __res
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue(0, kb_begin);  // weights and activations are in flight while the table is built
+    if (kb_begin < kb_end) issue(0, kb_begin);  // weights and activations are in flight while the table is built
     {   // every lane fetches the V entries of its own feature (rows of lut are 2V bytes, 4-byte aligned)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -124,15 +131,15 @@ __global__ __launch_bounds__(LW * 64) void lut_mfma_kernel(const uint16_t* __res
             for (int e = 0; e < V / 2; ++e) h[e] = lp[e];
 #pragma unroll
             for (int e = 0; e < V / 2; ++e) {
-                tbl[wv][t][2 * e][lane] = h[e] & 0xffffu;
-                tbl[wv][t][2 * e + 1][lane] = h[e] >> 16;
+                tbl[INWG ? 0 : wv][t][2 * e][lane] = h[e] & 0xffffu;  // INWG: every wave writes the same values
+                tbl[INWG ? 0 : wv][t][2 * e + 1][lane] = h[e] >> 16;
             }
         }
     }
     __syncthreads();  // tbl ready (each wave reads only its own part; the barrier orders the LDS writes)
 
     // LDS byte address of entry e: tb0 + 256*e + 4*lane (+ 256*V for tile 1)
-    const uint32_t tb0 = (uint32_t)(uintptr_t)(&tbl[0][0][0][0]) + (uint32_t)wv * (2u * V * 256u);
+    const uint32_t tb0 = (uint32_t)(uintptr_t)(&tbl[0][0][0][0]) + (INWG ? 0u : (uint32_t)wv * (2u * V * 256u));
     const uint32_t lane4 = 4u * lane;
     auto consume = [&](int buf) {
 #pragma unroll
@@ -187,6 +194,32 @@ __global__ __launch_bounds__(LW * 64) void lut_mfma_kernel(const uint16_t* __res
         if (bias) v += BF16 ? __builtin_bit_cast(float, (uint32_t)bias[o] << 16) : (float)__builtin_bit_cast(_Float16, bias[o]);
         y[(int64_t)row * m + o] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v) : __builtin_bit_cast(uint16_t, (_Float16)v);
     };
+    if constexpr (INWG) {
+        if (wv > 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) red[wv - 1][t][r][i][lane] = acc[t][r][i];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[t][r][i];
+#pragma unroll
+                        for (int w2 = 0; w2 < NW - 1; ++w2) v += red[w2][t][r][i][lane];  // fixed order
+                        const int row = 16 * r + 4 * q + i, o = o0 + 16 * t + col;
+                        if (row < M && o < m) finish(v, row, o);
+                    }
+        }
+        return;
+    }
     if (KS == 1) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -309,6 +342,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict_
 }
 
 struct LutPlan {
+    bool inwg;  // the waves of a workgroup split in_features among themselves (no exchange through memory)
     int ob, KS, kb_per_wg;
     size_t counter_bytes, bytes;
 };
@@ -317,6 +351,17 @@ static LutPlan lut_plan(int64_t M, int64_t m, int64_t n, int bits) {
     // (the partial tiles are KS*M*m floats and the last workgroup of a feature block sums KS of them)
     LutPlan p;
     const int nkb = (int)(n >> 5);
+    static const int inwg_env = getenv("GANQ_LUT_INWG") ? atoi(getenv("GANQ_LUT_INWG")) : -1;
+    // enough 32-feature workgroups to occupy the chip, and a reduction buffer that fits LDS (two row tiles)
+    p.inwg = inwg_env >= 0 ? (inwg_env != 0 && M <= 32) : (M <= 32 && (m + 31) / 32 >= 96);
+    if (p.inwg) {
+        p.ob = (int)((m + 31) / 32);
+        p.KS = 1;
+        p.kb_per_wg = (nkb + LWK - 1) / LWK;  // per wave
+        p.counter_bytes = align_up((size_t)p.ob * sizeof(int), 256);
+        p.bytes = p.counter_bytes;  // kept non-zero so that callers can reuse one workspace for every shape
+        return p;
+    }
     p.ob = (int)((m + LUT_FB - 1) / LUT_FB);
     static const int target_env = getenv("GANQ_LUT_WGS") ? atoi(getenv("GANQ_LUT_WGS")) : 0;
     // measured on MI355X (tools/lut_trace.sh): ~512 workgroups, and at most 8 / 4 / 2 splits for M <= 16 / 32 / 64 --
@@ -357,11 +402,24 @@ static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, con
     const uint16_t* lp = static_cast<const uint16_t*>(lut);
     const uint16_t* bp = static_cast<const uint16_t*>(bias);
     uint16_t* yp = static_cast<uint16_t*>(y);
+    if constexpr (RT <= 2) {
+        if (p.inwg) {
+            const dim3 g1((unsigned)p.ob, 1);
+            if (dtype == 1)
+                hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true, LWK, true>), g1, dim3(LWK * 64), 0, stream, xp, qw, lp, bp, M,
+                                   m, n, p.kb_per_wg, 1, partial, counters, yp);
+            else
+                hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false, LWK, true>), g1, dim3(LWK * 64), 0, stream, xp, qw, lp, bp, M,
+                                   m, n, p.kb_per_wg, 1, partial, counters, yp);
+            GANQ_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (dtype == 1)
-        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, M, m, n,
+        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true, LW, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, M, m, n,
                            p.kb_per_wg, p.KS, partial, counters, yp);
     else
-        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, M, m, n,
+        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false, LW, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, M, m, n,
                            p.kb_per_wg, p.KS, partial, counters, yp);
     GANQ_LAUNCH_CHECK();
     return 0;
