@@ -1,7 +1,8 @@
 """Per-architecture layer maps: where the repeating decoder layers live and which Linear modules of a layer are
-quantized in which order (modules of one group see the same inputs).  Same tables as the reference:
-  OPT    gptqmodel/models/definitions/opt.py:34-41
-  Llama  gptqmodel/models/definitions/llama.py:28-39
+quantized in which order (modules of one group see the same inputs).  Same tables as the reference's
+gptqmodel/models/definitions/*.py (opt.py:34-41, llama.py:28-39, ...), for the dense decoder families whose
+Hugging Face module names are listed below.  Mixture-of-experts families are not mapped (an expert that sees no
+calibration token has no Hessian; the reference special-cases that in its looper).
 """
 from dataclasses import dataclass
 from typing import List
@@ -26,7 +27,52 @@ LAYER_MAPS = {
         ["mlp.up_proj", "mlp.gate_proj"],
         ["mlp.down_proj"],
     ]),
+    "phi3": LayerMap("model.layers", [
+        ["self_attn.qkv_proj"],
+        ["self_attn.o_proj"],
+        ["mlp.gate_up_proj"],
+        ["mlp.down_proj"],
+    ]),
+    "starcoder2": LayerMap("model.layers", [
+        ["self_attn.k_proj", "self_attn.v_proj", "self_attn.q_proj"],
+        ["self_attn.o_proj"],
+        ["mlp.c_fc"],
+        ["mlp.c_proj"],
+    ]),
+    "gpt_neox": LayerMap("gpt_neox.layers", [
+        ["attention.query_key_value"],
+        ["attention.dense"],
+        ["mlp.dense_h_to_4h"],
+        ["mlp.dense_4h_to_h"],
+    ]),
+    "gptj": LayerMap("transformer.h", [
+        ["attn.k_proj", "attn.v_proj", "attn.q_proj"],
+        ["attn.out_proj"],
+        ["mlp.fc_in"],
+        ["mlp.fc_out"],
+    ]),
+    "falcon": LayerMap("transformer.h", [
+        ["self_attention.query_key_value"],
+        ["self_attention.dense"],
+        ["mlp.dense_h_to_4h"],
+        ["mlp.dense_4h_to_h"],
+    ]),
+    "bloom": LayerMap("transformer.h", [
+        ["self_attention.query_key_value"],
+        ["self_attention.dense"],
+        ["mlp.dense_h_to_4h"],
+        ["mlp.dense_4h_to_h"],
+    ]),
+    "gpt2": LayerMap("transformer.h", [  # transformers' Conv1D modules (weight stored [in, out])
+        ["attn.c_attn"],
+        ["attn.c_proj"],
+        ["mlp.c_fc"],
+        ["mlp.c_proj"],
+    ]),
 }
+# decoder layers with Llama's module names
+for _alias in ("mistral", "qwen2", "qwen3", "gemma", "gemma2", "granite", "olmo", "olmo2", "cohere", "stablelm", "yi"):
+    LAYER_MAPS[_alias] = LAYER_MAPS["llama"]
 
 
 def layer_map_for(model) -> LayerMap:

@@ -22,6 +22,61 @@ def tiny(kind):
     return transformers.LlamaForCausalLM(cfg).half().cuda().eval()
 
 
+FAMILIES = {
+    # model_type: (config class, model class, config kwargs, linear layers per decoder layer)
+    "mistral": ("MistralConfig", "MistralForCausalLM", dict(vocab_size=320, hidden_size=64, intermediate_size=128,
+                num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=128), 7),
+    "qwen2": ("Qwen2Config", "Qwen2ForCausalLM", dict(vocab_size=320, hidden_size=64, intermediate_size=128,
+              num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=128), 7),
+    "qwen3": ("Qwen3Config", "Qwen3ForCausalLM", dict(vocab_size=320, hidden_size=64, intermediate_size=128,
+              num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=16, max_position_embeddings=128), 7),
+    "gemma": ("GemmaConfig", "GemmaForCausalLM", dict(vocab_size=320, hidden_size=64, intermediate_size=128,
+              num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=16, max_position_embeddings=128), 7),
+    "phi3": ("Phi3Config", "Phi3ForCausalLM", dict(vocab_size=320, hidden_size=64, intermediate_size=128,
+             num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=128, pad_token_id=0), 4),
+    "gpt_neox": ("GPTNeoXConfig", "GPTNeoXForCausalLM", dict(vocab_size=320, hidden_size=64, intermediate_size=128,
+                 num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=128), 4),
+    "gptj": ("GPTJConfig", "GPTJForCausalLM", dict(vocab_size=320, n_embd=64, n_inner=128, n_layer=2, n_head=4,
+             n_positions=128, rotary_dim=16), 6),
+    "falcon": ("FalconConfig", "FalconForCausalLM", dict(vocab_size=320, hidden_size=64, num_hidden_layers=2,
+               num_attention_heads=4, max_position_embeddings=128), 4),
+    "bloom": ("BloomConfig", "BloomForCausalLM", dict(vocab_size=320, hidden_size=64, n_layer=2, n_head=4), 4),
+    "gpt2": ("GPT2Config", "GPT2LMHeadModel", dict(vocab_size=320, n_embd=64, n_layer=2, n_head=4, n_positions=128), 4),
+    "starcoder2": ("Starcoder2Config", "Starcoder2ForCausalLM", dict(vocab_size=320, hidden_size=64, intermediate_size=128,
+                   num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=128), 6),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(FAMILIES))
+@torch.no_grad()
+def test_quantize_model_other_families(kind):
+    # the layer maps beyond OPT / Llama: every mapped Linear of a tiny random model is quantized and the packed model
+    # reproduces the dequantised (FORMAT.FAKE) one
+    import copy
+
+    import transformers
+
+    from ganq_amd.models import quantize_model
+    from ganq_amd.nn_modules.qlinear.ganq_hip import GanqHipQuantLinear
+    from ganq_amd.quantization import QuantizeConfig
+
+    cfg_name, cls_name, kwargs, per_layer = FAMILIES[kind]
+    torch.manual_seed(0)
+    model = getattr(transformers, cls_name)(getattr(transformers, cfg_name)(**kwargs)).half().cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    calib = [torch.randint(1, 320, (2, 64), generator=g) for _ in range(3)]
+    fake = copy.deepcopy(model)
+    qcfg = QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2)
+    proc = quantize_model(model, calib, qcfg)
+    assert len(proc.results()) == 2 * per_layer
+    assert sum(isinstance(mod, GanqHipQuantLinear) for mod in model.modules()) == 2 * per_layer
+    quantize_model(fake, calib, QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2,
+                                               format="fake"))
+    x = calib[0][:1].cuda()
+    a, b = model(x).logits.float(), fake(x).logits.float()
+    assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("kind", ["opt", "llama"])
 @torch.no_grad()
 def test_quantize_model_save_load_ppl(kind, tmp_path):
