@@ -31,6 +31,7 @@ class GPTQProcessor:
         self.tasks: Dict[str, GANQ] = {}
         self._results: Dict[str, Dict[str, torch.Tensor]] = {}
         self.log = []  # one row per module, like the reference's quant_log (writer.py:54-60)
+        self.unquantized = []  # modules that saw no calibration data (MoE experts) and were left as they are
 
     def preprocess(self, module: NamedModule, buffered_fwd: bool = False):
         if self.qcfg.dynamic_get(layer_name=module.full_name) is False:  # '-:' pattern: module skipped
@@ -44,6 +45,14 @@ class GPTQProcessor:
             tmp.fwd_inputs_buffered = True
         tmp.quantizer.configure(perchannel=True)
         self.tasks[module.name] = tmp
+
+    def skip(self, module: NamedModule):
+        """Drop a prepared module without quantizing it (it saw no calibration data)."""
+        g = self.tasks.pop(module.name, None)
+        if g:
+            g.free()
+        self.tasks[module.name] = False
+        self.unquantized.append(module.full_name)
 
     def is_skipped(self, module: NamedModule) -> bool:
         return self.tasks.get(module.name, False) is False

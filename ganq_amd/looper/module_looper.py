@@ -14,6 +14,8 @@ with identical quantized layers ("looper dispatches layers over RCCL ranks").
 """
 from typing import Callable, Dict, List, Optional, Sequence
 
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -28,10 +30,12 @@ def find_modules(layer: nn.Module, names: Sequence[str]) -> Dict[str, nn.Module]
 
 class ModuleLooper:
     def __init__(self, processor, layers: Sequence[nn.Module], layer_modules: List[List[str]],
-                 layers_prefix: str = "model.layers", share_group_hessian: bool = True):
+                 layers_prefix: str = "model.layers", share_group_hessian: bool = False):
         # share_group_hessian: the modules of one group ([q,k,v], [gate,up]) receive the same inputs, so the first
         # one accumulates the Hessian and runs the prologue (permutation, factor, damping) for all of them; the
-        # reference does both once per module.  Same numbers, less work.
+        # reference does both once per module.  Same numbers, less work.  Only valid when the groups really share
+        # their inputs (dense q/k/v, gate/up): the experts of a mixture-of-experts group do not -- hence opt-in; the
+        # layer maps of ganq_amd.models say which it is.
         self.share_group_hessian = share_group_hessian
         self.processor = processor
         self.layers = layers
@@ -82,8 +86,13 @@ class ModuleLooper:
                     lead = getattr(task, "_group_leader", None)
                     if lead is not None:
                         task.fwd_counter, task.nsamples = lead.fwd_counter, lead.nsamples
-                    if task.fwd_counter == 0:  # module never hit (module_looper.py:335-343)
-                        raise RuntimeError(f"module {named[n].full_name} saw no calibration activations")
+                    if task.fwd_counter == 0:
+                        # never invoked (an expert no calibration token was routed to): like the reference
+                        # (module_looper.py:332-343) report it and leave the module as it is
+                        warnings.warn(f"`{named[n].full_name}` was not invoked during calibration and stays unquantized "
+                                      f"(a MoE expert may lack calibration tokens routed to it)")
+                        self.processor.skip(named[n])
+                        continue
                     self.processor.process(named[n])
                     if progress:
                         progress(named[n])

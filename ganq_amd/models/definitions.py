@@ -1,8 +1,10 @@
 """Per-architecture layer maps: where the repeating decoder layers live and which Linear modules of a layer are
 quantized in which order (modules of one group see the same inputs).  Same tables as the reference's
 gptqmodel/models/definitions/*.py (opt.py:34-41, llama.py:28-39, ...), for the dense decoder families whose
-Hugging Face module names are listed below.  Mixture-of-experts families are not mapped (an expert that sees no
-calibration token has no Hessian; the reference special-cases that in its looper).
+Hugging Face module names are listed below.  Mixture-of-experts families are not mapped: this transformers
+version fuses the experts into 3-D parameters instead of per-expert nn.Linear modules.  (The looper itself handles
+non-shared groups -- `shared_group_inputs=False` -- and reports modules no calibration token reached, as the
+reference's does.)
 """
 from dataclasses import dataclass
 from typing import List
@@ -12,6 +14,7 @@ from typing import List
 class LayerMap:
     layers_node: str
     layer_modules: List[List[str]]
+    shared_group_inputs: bool = True  # the modules of a group receive the same tensor (dense decoders); False for MoE experts
 
 
 LAYER_MAPS = {

@@ -76,7 +76,8 @@ def quantize_model(model: nn.Module, calibration: Sequence[torch.Tensor], qcfg: 
     def fwd(layer, x, kw):
         return layer(x, **kw)
 
-    ModuleLooper(proc, layers, lm.layer_modules, layers_prefix=lm.layers_node).loop(hidden, kwargs_list, forward=fwd,
+    ModuleLooper(proc, layers, lm.layer_modules, layers_prefix=lm.layers_node,
+                 share_group_hessian=lm.shared_group_inputs).loop(hidden, kwargs_list, forward=fwd,
                                                                                   progress=progress)
     proc.finalize(model)
     model.quantize_config = qcfg

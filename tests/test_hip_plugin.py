@@ -168,6 +168,34 @@ def test_looper_shared_group_hessian_is_identical():
         assert torch.equal(res[0][k][0], res[1][k][0]) and torch.equal(res[0][k][1], res[1][k][1]), k
 
 
+@torch.no_grad()
+def test_looper_reports_modules_without_calibration_data():
+    # a module of a group that is never invoked (MoE expert without routed tokens) is reported and left as it is
+    from ganq_amd.looper.gptq_processor import GPTQProcessor
+    from ganq_amd.looper.module_looper import ModuleLooper
+    from ganq_amd.quantization import QuantizeConfig
+
+    class Layer(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Linear(64, 64), nn.Linear(64, 64)
+
+        def forward(self, x):
+            return x + self.a(x)  # self.b is never called
+
+    torch.manual_seed(0)
+    model = nn.Module()
+    model.layers = nn.ModuleList([Layer()])
+    model = model.half().cuda()
+    xs = [torch.randn(2, 32, 64, device="cuda").half() for _ in range(2)]
+    proc = GPTQProcessor(QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2))
+    with pytest.warns(UserWarning, match="was not invoked"):
+        ModuleLooper(proc, model.layers, [["a", "b"]], layers_prefix="layers").loop(xs)
+    assert list(proc.results()) == ["layers.0.a"] and proc.unquantized == ["layers.0.b"]
+    proc.finalize(model)
+    assert isinstance(model.layers[0].b, nn.Linear)
+
+
 @pytest.mark.parametrize("bits,rows", [(4, 1), (4, 40), (3, 7), (2, 16)])
 def test_quantlinear_pack_forward_and_state_dict(bits, rows):
     from ganq_amd.nn_modules.qlinear.ganq_hip import GanqHipQuantLinear
