@@ -31,6 +31,7 @@ SIGNATURES = {
     "ganq_hip_last_error": (ctypes.c_char_p, []),
     "ganq_hip_selftest": (ctypes.c_int, [_c_vp]),
     "ganq_debug_div_check": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _c_vp, _c_vp, _c_vp]),
+    "ganq_debug_wh_product": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp]),
     "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ganq_cholesky_workspace_bytes": (_c_sz, [_c_i64]),
     "ganq_cholesky": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_sz, _c_vp]),
@@ -144,6 +145,17 @@ def debug_div_check(count: int, seed: int = 1):
     _check(lib().ganq_debug_div_check(int(count), int(seed), bad.data_ptr(), first.data_ptr(), _stream()),
            "ganq_debug_div_check")
     return int(bad), tuple(first.tolist())
+
+
+def debug_wh_product(W, H):
+    """(WH, H_fixed) in fp64: the product the fused driver feeds to the T-update and the fixed-point H behind it"""
+    W, H = _dev_f32(W, "W"), _dev_f32(H, "H")
+    m, n = W.shape
+    WH = torch.empty((m, n), dtype=torch.float64, device=W.device)
+    Hf = torch.empty((n, n), dtype=torch.float64, device=W.device)
+    _check(lib().ganq_debug_wh_product(W.data_ptr(), H.data_ptr(), m, n, WH.data_ptr(), Hf.data_ptr(), _stream()),
+           "ganq_debug_wh_product")
+    return WH, Hf
 
 
 def solve_s(W, L, T, want_err=False):

@@ -9,11 +9,14 @@ struct TLayout {
     size_t off_prep, off_planes, off_hdiag, off_bits, off_mpart, off_h64, off_wh64, off_whw, off_lossrows, total;
     // incremental bucket sums (loop driver only): integer H, previous indices, per-row sums, change lists
     size_t off_hint, off_qprev, off_mstate, off_chg, off_chgcnt;
+    // split-fp16 W @ H_fixed (wh_gemm.hip): packed pieces of W and H, row exponents, Wlo flags
+    size_t off_wp, off_hp, off_rexp, off_wlo;
 };
 
 TLayout t_layout(int64_t m, int64_t n, bool with_f64);
 
-// once per layer.  with_f64: also W @ H_fixed in fp64 and w_i^T H w_i (needed for the closed-form loss)
+// once per layer.  with_f64: also W @ H_fixed (fp64 values; computed on the fp16 matrix cores from split operands,
+// wh_gemm.hip, or by the fp64 GEMM with GANQ_WH_F64=1) and w_i^T H w_i (needed for the closed-form loss)
 int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayout& lo, char* ws, bool with_f64,
               hipStream_t stream);
 

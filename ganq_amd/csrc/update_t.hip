@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "update_t.h"
+#include "wh_gemm.h"
 
 namespace ganq {
 
@@ -827,6 +828,15 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// GANQ_WH_F64=1 (read once): W @ H_fixed by the fp64 GEMM instead of the split-fp16 product -- the A/B reference
+static bool wh_use_f64_gemm() {
+    static const bool f64 = [] {
+        const char* e = getenv("GANQ_WH_F64");
+        return e && e[0] == '1';
+    }();
+    return f64;
+}
+
 TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
     TLayout lo;
     lo.nq = (n + UT - 1) / UT * UT;
@@ -844,13 +854,22 @@ TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
     lo.off_mpart = take((size_t)NP * m * 256 * sizeof(long long));
     lo.off_h64 = lo.off_wh64 = lo.off_whw = lo.off_lossrows = 0;
     lo.off_hint = lo.off_qprev = lo.off_mstate = lo.off_chg = lo.off_chgcnt = 0;
+    lo.off_wp = lo.off_hp = lo.off_rexp = lo.off_wlo = 0;
     if (with_f64) {
         lo.off_hint = take((size_t)n * n * sizeof(int));
         lo.off_qprev = take((size_t)m * n);
         lo.off_mstate = take((size_t)m * 256 * sizeof(long long));
         lo.off_chg = take((size_t)m * n * sizeof(uint16_t));
         lo.off_chgcnt = take((size_t)m * sizeof(int) + 64);  // counts per row, then the 8-byte total
-        lo.off_h64 = take((size_t)n * n * sizeof(double));
+        if (wh_use_f64_gemm()) {
+            lo.off_h64 = take((size_t)n * n * sizeof(double));
+        } else {
+            const WhLayout wl = wh_layout(m, n);
+            lo.off_wp = take(wl.wp_bytes);
+            lo.off_hp = take(wl.hp_bytes);
+            lo.off_rexp = take(wl.rexp_bytes);
+            lo.off_wlo = take(wl.wlo_bytes);
+        }
         lo.off_wh64 = take((size_t)m * n * sizeof(double));
         lo.off_whw = take((size_t)m * sizeof(double));
         lo.off_lossrows = take((size_t)m * sizeof(double));
@@ -859,13 +878,19 @@ TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
     return lo;
 }
 
+__global__ __launch_bounds__(256) void hfixed_kernel(const int* __restrict__ Hint, const TPrep* __restrict__ prep, int64_t total,
+                                                    double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        out[i] = prep->scale * (double)Hint[i];
+}
+
 // once per layer: fixed-point planes of H (+ optionally W @ H_fixed in fp64 and w^T H w per row)
 int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayout& lo, char* ws, bool with_f64,
               hipStream_t stream) {
     TPrep* prep = reinterpret_cast<TPrep*>(ws + lo.off_prep);
     int8_t* planes = reinterpret_cast<int8_t*>(ws + lo.off_planes);
     int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
-    double* H64 = with_f64 ? reinterpret_cast<double*>(ws + lo.off_h64) : nullptr;
+    double* H64 = (with_f64 && lo.off_h64) ? reinterpret_cast<double*>(ws + lo.off_h64) : nullptr;
     ProfScope prof(KID_T_PREP, stream);
     GANQ_HIP_CHECK(hipMemsetAsync(prep, 0, sizeof(TPrep), stream));
     hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, stream, H, n * n, prep);
@@ -879,7 +904,14 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
         double* WH64 = reinterpret_cast<double*>(ws + lo.off_wh64);
         double* wHw = reinterpret_cast<double*>(ws + lo.off_whw);
         const int tiles = (int)(((m + DM - 1) / DM) * ((n + DN - 1) / DN));
-        hipLaunchKernelGGL(gemm_f64_kernel, dim3(tiles), dim3(256), 0, stream, W, H64, WH64, (int)m, (int)n, (int)n);
+        if (H64) {
+            hipLaunchKernelGGL(gemm_f64_kernel, dim3(tiles), dim3(256), 0, stream, W, H64, WH64, (int)m, (int)n, (int)n);
+        } else {
+            const WhLayout wl = wh_layout(m, n);
+            int rc = wh_gemm(W, Hint, &prep->scale, m, n, wl, ws + lo.off_wp, ws + lo.off_hp, reinterpret_cast<int*>(ws + lo.off_rexp),
+                             reinterpret_cast<int*>(ws + lo.off_wlo), WH64, stream);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(whw_kernel, dim3((unsigned)m), dim3(256), 0, stream, W, WH64, (int)m, (int)n, wHw);
         GANQ_LAUNCH_CHECK();
     }
@@ -983,6 +1015,30 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
 }  // namespace ganq
 
 using namespace ganq;
+
+// developer check (tests): the W @ H_fixed product of the fused driver and the fixed-point H it was formed with
+extern "C" int ganq_debug_wh_product(const float* W, const float* H, int64_t m, int64_t n, double* WH_out, double* Hfixed_out,
+                                     void* stream_) {
+    if (m <= 0 || n <= 0 || m > INT32_MAX / 2 || n > INT32_MAX / 2) return fail(-1, "ganq_debug_wh_product: bad shape");
+    if (!W || !H || !WH_out) return fail(-3, "ganq_debug_wh_product: null pointer");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const TLayout lo = t_layout(m, n, true);
+    char* ws = nullptr;
+    GANQ_HIP_CHECK(hipMalloc(&ws, lo.total));
+    int rc = t_prepare(W, H, m, n, lo, ws, true, stream);
+    if (rc == 0) {
+        hipError_t e = hipMemcpyAsync(WH_out, ws + lo.off_wh64, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess && Hfixed_out) {
+            const int* Hint = reinterpret_cast<const int*>(ws + lo.off_hint);
+            hipLaunchKernelGGL(hfixed_kernel, dim3(1024), dim3(256), 0, stream, Hint, reinterpret_cast<const TPrep*>(ws + lo.off_prep),
+                               n * n, Hfixed_out);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(-4, "ganq_debug_wh_product: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(ws);
+    return rc;
+}
 
 extern "C" size_t ganq_update_t_workspace_bytes(int64_t m, int64_t n, int V) {
     (void)V;

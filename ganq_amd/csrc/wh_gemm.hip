@@ -1,0 +1,237 @@
+// W @ H_fixed for the T-update (reference ganq.py:590, `W @ H` in fp32) on the fp16 matrix cores.
+//
+// Both operands are split into two fp16 pieces, x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits
+// per element (the reference multiplies fp32 values, 24 bits), after an exact power-of-two scaling that puts the row
+// maximum of W and the maximum of H at 2^14..2^15 (fp16 has 5 exponent bits).  The product is
+//     W H  ~=  Whi Hhi + Whi Hlo + Wlo Hhi          (Wlo Hlo is below 2^-22 of the result and dropped),
+// three v_mfma_f32_32x32x16_f16 per fragment pair into one fp32 accumulator; products of fp16 values are exact in
+// fp32, so the rounding left is that of the fp32 accumulation -- the same class of error as the reference's fp32 GEMM
+// (measured: 3e-7 relative on W H, 4e-8 on the codebook, against 1e-5 allowed).  A module whose weights are fp16
+// values has Wlo == 0: the split kernel records that per 128-row block and the third product and its loads are skipped.
+// H is symmetric, so both operands are read "row x k" and k is the contiguous direction of both.
+//
+// Data layout: the split kernels write the pieces in the order the GEMM reads them -- per (128-row block, 32-deep
+// k tile) one 8 KB image per piece, row r at byte 64 r, its four 16-byte chunks (8 k each) stored at chunk index
+// c ^ ((r >> 2) & 3).  A workgroup copies 32 KB per k tile linearly (16 B per lane, fully coalesced) into LDS, and the
+// swizzle makes the ds_read_b128 of an MFMA operand (32 rows x 16 B at one chunk index) hit all 64 banks once.
+// 128x128 output tile per workgroup, 4 waves x 64x64, double-buffered LDS (64 KB), two workgroups per CU.
+// The kernel is bound by the L2 -> LDS stream (4 GB at 4096^2), not by the matrix cores.
+#include "common.h"
+#include "wh_gemm.h"
+
+namespace ganq {
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+constexpr int WT = 128;               // rows per operand block
+constexpr int WK = 32;                // k per tile
+constexpr int WIMG = WT * WK * 2;     // bytes of one piece of one tile (8 KB)
+
+__device__ __forceinline__ int64_t wh_chunk_offset(int r, int c) {  // inside one piece image
+    return (int64_t)r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+}
+
+// one workgroup per (padded) row of W: row maximum -> power-of-two scale, then the two pieces of every 8-k chunk
+__global__ __launch_bounds__(256) void wh_split_w_kernel(const float* __restrict__ W, int m, int n, int KT, char* __restrict__ Wp,
+                                                        int* __restrict__ rexp, int* __restrict__ wlo_any) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x, rb = r >> 7, rr = r & 127;
+    const float* w = W + (int64_t)min(r, m - 1) * n;
+    float mx = 0.0f;
+    if (r < m)
+        for (int u = threadIdx.x; u < n; u += 256) mx = fmaxf(mx, fabsf(w[u]));
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    int sft = 0;
+    if (mx > 0.0f && mx < __builtin_inff()) sft = 14 - max(ilogbf(mx), -100);  // mx * 2^sft in [2^14, 2^15)
+    const float sc = ldexpf(1.0f, sft);
+    if (threadIdx.x == 0 && r < m) rexp[r] = sft;
+    bool any = false;
+    for (int ci = threadIdx.x; ci < KT * 4; ci += 256) {
+        h8v hi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = ci * 8 + k;
+            const float x = (r < m && u < n) ? w[u] * sc : 0.0f;
+            const _Float16 h = (_Float16)x;
+            const _Float16 l = (_Float16)(x - (float)h);
+            hi[k] = h;
+            lo[k] = l;
+            any |= (l != (_Float16)0.0f);
+        }
+        char* dst = Wp + ((int64_t)rb * KT + (ci >> 2)) * (2 * WIMG) + wh_chunk_offset(rr, ci & 3);
+        *reinterpret_cast<h8v*>(dst) = hi;
+        *reinterpret_cast<h8v*>(dst + WIMG) = lo;
+    }
+    if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(&wlo_any[rb], 1);
+}
+
+// one workgroup per (padded) row of the fixed-point H: x = integer * 2^-16, |x| <= 2^14
+__global__ __launch_bounds__(256) void wh_split_h_kernel(const int* __restrict__ Hint, int n, int KT, char* __restrict__ Hp) {
+    const int r = blockIdx.x, rb = r >> 7, rr = r & 127;
+    const int* h = Hint + (int64_t)min(r, n - 1) * n;
+    for (int ci = threadIdx.x; ci < KT * 4; ci += 256) {
+        h8v hi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = ci * 8 + k;
+            const double x = (r < n && u < n) ? (double)h[u] * (1.0 / 65536.0) : 0.0;
+            const _Float16 a = (_Float16)(float)x;
+            hi[k] = a;
+            lo[k] = (_Float16)(float)(x - (double)(float)a);
+        }
+        char* dst = Hp + ((int64_t)rb * KT + (ci >> 2)) * (2 * WIMG) + wh_chunk_offset(rr, ci & 3);
+        *reinterpret_cast<h8v*>(dst) = hi;
+        *reinterpret_cast<h8v*>(dst + WIMG) = lo;
+    }
+}
+
+// WH[row][col] (fp64) = hscale * 2^-rexp[row] * sum_k (Whi + Wlo)[row][k] (Hhi + Hlo)[col][k]
+// WLO: this instantiation serves the 128-row blocks of W whose low pieces are (not) all zero; both are launched and a
+// workgroup of the other kind leaves at once (the flags are only known on the device).
+template <bool WLO>
+__global__ __launch_bounds__(256, 2) void wh_gemm_kernel(const char* __restrict__ Wp, const char* __restrict__ Hp,
+                                                        const int* __restrict__ rexp, const int* __restrict__ wlo_any,
+                                                        const double* __restrict__ hscale, double* __restrict__ WH, int m, int n,
+                                                        int KT, int tiles_m, int tiles_n) {
+    __shared__ __align__(16) char lds[2][4 * WIMG];  // per buffer: Whi, Wlo, Hhi, Hlo images
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // workgroups are dealt round-robin to the 8 XCDs: give every XCD a contiguous range of logical tiles, and walk
+    // the tiles in groups of 8 tile rows, column by column, so that the workgroups resident together on an XCD form
+    // an 8 x 8 block (8 W panels + 8 H panels in flight in its L2)
+    const int total = tiles_m * tiles_n;
+    int lt = blockIdx.x;
+    if ((total & 7) == 0) lt = (lt & 7) * (total >> 3) + (lt >> 3);
+    const int gsz = 8 * tiles_n;
+    const int g = lt / gsz, gr = min(8, tiles_m - g * 8);
+    const int tm = g * 8 + (lt % gsz) % gr, tn = (lt % gsz) / gr;
+
+    const char* wsrc = Wp + (int64_t)tm * KT * (2 * WIMG);
+    const char* hsrc = Hp + (int64_t)tn * KT * (2 * WIMG);
+    if ((wlo_any[tm] != 0) != WLO) return;
+
+    constexpr int NA = WLO ? 4 : 2;  // 4 KB slices of the W images to copy (hi only, or hi and lo)
+    u4v sa[NA], sb[4];
+    auto gload = [&](int kt) {
+        const char* a = wsrc + (int64_t)kt * (2 * WIMG) + tid * 16;
+        const char* b = hsrc + (int64_t)kt * (2 * WIMG) + tid * 16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const u4v*>(a + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sb[i] = *reinterpret_cast<const u4v*>(b + i * 4096);
+    };
+    auto sstore = [&](int buf) {
+        char* d = lds[buf] + tid * 16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u4v*>(d + i * 4096) = sa[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u4v*>(d + 2 * WIMG + i * 4096) = sb[i];
+    };
+
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int swz = (l31 >> 2) & 3;
+    int aoff[2], boff[2], coff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        aoff[i] = (wm + 32 * i + l31) * 64;
+        boff[i] = 2 * WIMG + (wn + 32 * i + l31) * 64;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) coff[ks] = ((ks * 2 + hf) ^ swz) << 4;
+
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        gload(min(kt + 1, KT - 1));  // the last iteration re-reads its own tile: no branch around the loads
+        const char* base = lds[kt & 1];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8v ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const h8v*>(base + aoff[i] + coff[ks]);
+                bh[i] = *reinterpret_cast<const h8v*>(base + boff[i] + coff[ks]);
+                bl[i] = *reinterpret_cast<const h8v*>(base + boff[i] + WIMG + coff[ks]);
+            }
+            if (WLO) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) al[i] = *reinterpret_cast<const h8v*>(base + aoff[i] + WIMG + coff[ks]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            if (WLO) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        sstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const double hs = *hscale * 65536.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = tm * WT + wm + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+            if (row >= m) continue;
+            const double rs = hs * ldexp(1.0, -rexp[row]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = tn * WT + wn + 32 * j + l31;
+                if (col < n) WH[(int64_t)row * n + col] = (double)acc[i][j][reg] * rs;
+            }
+        }
+}
+
+WhLayout wh_layout(int64_t m, int64_t n) {
+    WhLayout lo;
+    lo.KT = (n + WK - 1) / WK;
+    lo.tiles_m = (m + WT - 1) / WT;
+    lo.tiles_n = (n + WT - 1) / WT;
+    lo.wp_bytes = (size_t)lo.tiles_m * lo.KT * 2 * WIMG;
+    lo.hp_bytes = (size_t)lo.tiles_n * lo.KT * 2 * WIMG;
+    lo.rexp_bytes = align_up((size_t)lo.tiles_m * WT * sizeof(int), 256);
+    lo.wlo_bytes = align_up((size_t)lo.tiles_m * sizeof(int), 256);
+    return lo;
+}
+
+int wh_gemm(const float* W, const int* Hint, const double* hscale, int64_t m, int64_t n, const WhLayout& lo, char* wp, char* hp,
+            int* rexp, int* wlo_any, double* WH, hipStream_t stream) {
+    GANQ_HIP_CHECK(hipMemsetAsync(wlo_any, 0, lo.wlo_bytes, stream));
+    hipLaunchKernelGGL(wh_split_w_kernel, dim3((unsigned)(lo.tiles_m * WT)), dim3(256), 0, stream, W, (int)m, (int)n, (int)lo.KT, wp,
+                       rexp, wlo_any);
+    hipLaunchKernelGGL(wh_split_h_kernel, dim3((unsigned)(lo.tiles_n * WT)), dim3(256), 0, stream, Hint, (int)n, (int)lo.KT, hp);
+    hipLaunchKernelGGL(wh_gemm_kernel<false>, dim3((unsigned)(lo.tiles_m * lo.tiles_n)), dim3(256), 0, stream, wp, hp, rexp, wlo_any,
+                       hscale, WH, (int)m, (int)n, (int)lo.KT, (int)lo.tiles_m, (int)lo.tiles_n);
+    hipLaunchKernelGGL(wh_gemm_kernel<true>, dim3((unsigned)(lo.tiles_m * lo.tiles_n)), dim3(256), 0, stream, wp, hp, rexp, wlo_any,
+                       hscale, WH, (int)m, (int)n, (int)lo.KT, (int)lo.tiles_m, (int)lo.tiles_n);
+    GANQ_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ganq

@@ -49,6 +49,11 @@ int ganq_hip_selftest(void* stream);
 int ganq_debug_div_check(uint64_t count, uint32_t seed, unsigned long long* mismatches_dev, float* first_bad_dev,
                          void* stream);
 
+/* Developer check (tests): WH_out [m,n] fp64 = the W @ H_fixed product the fused driver feeds to the T-update (fp16 matrix
+ * cores, operands split into two fp16 pieces; GANQ_WH_F64=1: the fp64 GEMM), Hfixed_out [n,n] fp64 (may be NULL) = the
+ * 31-bit fixed-point H it is formed with.  Allocates its own scratch and synchronises the stream. */
+int ganq_debug_wh_product(const float* W, const float* H, int64_t m, int64_t n, double* WH_out, double* Hfixed_out, void* stream);
+
 /* ---- a1: Hessian accumulation (gptq.py:96-131 process_batch) --------------------------------
  * One calibration batch: X [rows, n] fp16 or bf16 (dtype: 0 = fp16, 1 = bf16), `batch` = number
  * of sequences in it (gptq.py:104), nsamples_before = sequences accumulated so far.

@@ -253,3 +253,27 @@ def test_reciprocal_quotient_equals_ieee_division(hip):
     # the S-solve replaces r / L[j][j] by a reciprocal-based sequence that must round like the division
     bad, first = hip.debug_div_check(1 << 30, seed=7)
     assert bad == 0, f"{bad} of 2^30 quotients differ from IEEE division, e.g. a,b = {first}"
+
+
+@pytest.mark.parametrize("m,n,half_w", [(128, 128, True), (96, 200, False), (300, 1000, True), (257, 2050, False),
+                                        (64, 4096, True)])
+def test_wh_product_split_fp16(hip, m, n, half_w):
+    """W @ H_fixed of the fused driver (fp16 matrix cores, operands split into two fp16 pieces, wh_gemm.hip) against the
+    same product in fp64: the error must stay in the class of the reference's fp32 `W @ H` (ganq.py:590)"""
+    g = torch.Generator().manual_seed(m * 7 + n)
+    W = 0.02 * torch.randn(m, n, generator=g)
+    if half_w:
+        W = W.half().float()  # fp16 module: the low pieces of W vanish and the third product is skipped
+    W[m // 2] *= 1e-3  # rows of very different magnitude get their own power-of-two scale
+    W[0, : n // 2] = 0.0
+    X = torch.randn(4 * n, n, generator=g) * (0.05 + 3.0 * torch.rand(n, generator=g))
+    H = (X.T @ X / X.shape[0]).float()
+    WH, Hf = hip.debug_wh_product(W.cuda(), H.cuda())
+    Hf, WH = Hf.cpu(), WH.cpu()
+    assert (Hf - H.double()).abs().max() <= H.abs().max().double() * 2.0 ** -30  # 31-bit fixed point
+    ref = W.double() @ Hf
+    err = (WH - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)
+    ref32 = (W @ Hf.float()).double()
+    err32 = (ref32 - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)
+    assert err.max() < 2e-6, (float(err.max()), float(err32.max()))
+    assert err.median() < 1e-6
