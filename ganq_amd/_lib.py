@@ -57,7 +57,12 @@ SIGNATURES = {
     "ganq_lut_linear_workspace_init": (ctypes.c_int, [_c_vp, _c_sz, _c_vp]),
     "ganq_lut_linear_fwd": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64,
                                            ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ganq_lut_linear_fwd_add": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64,
+                                               ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_lut_dequant": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
+    "ganq_outlier_cutoffs": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "ganq_outlier_extract": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "ganq_outlier_matmul": (ctypes.c_int, [_c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "ganq_pack_indices": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
     "ganq_unpack_indices": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
     "ganq_profile_enable": (ctypes.c_int, [ctypes.c_int]),
@@ -375,8 +380,43 @@ def _lut_workspace(nbytes: int, device):
     return ws
 
 
-def lut_linear(x, qweight, lut, bias, bits: int):
-    """x [M,n] (M <= 64) fp16/bf16, qweight int32 [n*bits/32, m], lut [m,V], bias [m] or None -> y [M,m]."""
+def outlier_split(W, ratio: float):
+    """Algorithm 2 of the paper on the device.  W [m,n] fp32 is overwritten by W_dense (outliers zeroed); returns the
+    outliers as CSR (rowptr int32 [m+1], cols int32 [nnz] ascending per row, vals fp32 [nnz]) and the cut-offs [m,2]."""
+    W = _dev_f32(W, "W")
+    m, n = W.shape
+    cut = torch.empty((m, 2), dtype=torch.float32, device=W.device)
+    counts = torch.empty((m,), dtype=torch.int32, device=W.device)
+    rowptr = torch.empty((m + 1,), dtype=torch.int32, device=W.device)
+    _check(lib().ganq_outlier_cutoffs(W.data_ptr(), m, n, float(ratio), cut.data_ptr(), counts.data_ptr(), rowptr.data_ptr(),
+                                      _stream()), "ganq_outlier_cutoffs")
+    nnz = int(rowptr[m])  # the one host read: sizes of the CSR arrays
+    cols = torch.empty((nnz,), dtype=torch.int32, device=W.device)
+    vals = torch.empty((nnz,), dtype=torch.float32, device=W.device)
+    if nnz:
+        _check(lib().ganq_outlier_extract(W.data_ptr(), m, n, cut.data_ptr(), rowptr.data_ptr(), cols.data_ptr(), vals.data_ptr(),
+                                          _stream()), "ganq_outlier_extract")
+    return rowptr, cols, vals, cut
+
+
+def outlier_matmul(x, rowptr, cols, vals, m: int):
+    """x [M,n] fp16/bf16, CSR outliers of a [m,n] weight (vals in x's dtype) -> fp32 [M,m] = x @ W_sparse^T"""
+    code = _act_dtype(x, "x")
+    if vals.dtype != x.dtype or rowptr.dtype != torch.int32 or cols.dtype != torch.int32:
+        raise GanqHipError("outlier_matmul: vals must have x's dtype, rowptr / cols must be int32")
+    if rowptr.numel() != m + 1:
+        raise GanqHipError("outlier_matmul: rowptr must have out_features + 1 entries")
+    x = x.contiguous()
+    M, n = x.shape
+    out = torch.empty((M, m), dtype=torch.float32, device=x.device)
+    _check(lib().ganq_outlier_matmul(x.data_ptr(), code, M, m, n, rowptr.data_ptr(), _ptr(cols) if cols.numel() else None,
+                                     _ptr(vals) if vals.numel() else None, out.data_ptr(), _stream()), "ganq_outlier_matmul")
+    return out
+
+
+def lut_linear(x, qweight, lut, bias, bits: int, addend=None):
+    """x [M,n] (M <= 64) fp16/bf16, qweight int32 [n*bits/32, m], lut [m,V], bias [m] or None -> y [M,m].
+    addend: optional fp32 [M,m] added before the rounding to x's dtype (the sparse-outlier product)."""
     code = _act_dtype(x, "x")
     if lut.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype):
         raise GanqHipError("x, lut and bias must share one dtype")
@@ -385,6 +425,13 @@ def lut_linear(x, qweight, lut, bias, bits: int):
     m = lut.shape[0]
     y = torch.empty((M, m), dtype=x.dtype, device=x.device)
     ws = _lut_workspace(lib().ganq_lut_linear_workspace_bytes(M, m, n, bits), x.device)
+    if addend is not None:
+        if addend.dtype != torch.float32 or tuple(addend.shape) != (M, m) or not addend.is_contiguous():
+            raise GanqHipError("lut_linear: addend must be a contiguous fp32 [M, out_features] tensor")
+        _check(lib().ganq_lut_linear_fwd_add(x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), addend.data_ptr(), code,
+                                             M, m, n, bits, y.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "ganq_lut_linear_fwd_add")
+        return y
     _check(lib().ganq_lut_linear_fwd(x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), code, M, m, n, bits,
                                      y.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ganq_lut_linear_fwd")
     return y

@@ -70,7 +70,8 @@ __device__ __forceinline__ uint32_t lds_pair(uint32_t addr_lo, uint32_t addr_hi)
 template <int BITS, int RT, bool BF16, int NW, bool INWG>
 __global__ __launch_bounds__(NW * 64) void lut_mfma_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                           const uint16_t* __restrict__ lut, const uint16_t* __restrict__ bias,
-                                                          int M, int m, int n, int kb_per_wg, int KS,
+                                                          const float* __restrict__ addend, int M, int m, int n, int kb_per_wg,
+                                                          int KS,
                                                           float* __restrict__ partial, int* __restrict__ counters,
                                                           uint16_t* __restrict__ y) {
     constexpr int V = 1 << BITS;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(NW * 64) void lut_mfma_kernel(const uint16_t* __res
     }
 
     auto finish = [&](float v, int row, int o) {
+        if (addend) v += addend[(int64_t)row * m + o];  // fp32 [M, m]: the sparse-outlier product (outlier.hip)
         if (bias) v += BF16 ? __builtin_bit_cast(float, (uint32_t)bias[o] << 16) : (float)__builtin_bit_cast(_Float16, bias[o]);
         y[(int64_t)row * m + o] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v) : __builtin_bit_cast(uint16_t, (_Float16)v);
     };
@@ -395,7 +397,8 @@ extern "C" int ganq_lut_linear_workspace_init(void* workspace, size_t workspace_
 }
 
 template <int BITS, int RT>
-static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, const void* bias, int dtype, int M, int m, int n,
+static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, int dtype, int M,
+                         int m, int n,
                          const LutPlan& p, float* partial, int* counters, void* y, hipStream_t stream) {
     const dim3 grid((unsigned)p.ob, (unsigned)p.KS);
     const uint16_t* xp = static_cast<const uint16_t*>(x);
@@ -406,31 +409,32 @@ static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, con
         if (p.inwg) {
             const dim3 g1((unsigned)p.ob, 1);
             if (dtype == 1)
-                hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true, LWK, true>), g1, dim3(LWK * 64), 0, stream, xp, qw, lp, bp, M,
+                hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true, LWK, true>), g1, dim3(LWK * 64), 0, stream, xp, qw, lp, bp, addend, M,
                                    m, n, p.kb_per_wg, 1, partial, counters, yp);
             else
-                hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false, LWK, true>), g1, dim3(LWK * 64), 0, stream, xp, qw, lp, bp, M,
+                hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false, LWK, true>), g1, dim3(LWK * 64), 0, stream, xp, qw, lp, bp, addend, M,
                                    m, n, p.kb_per_wg, 1, partial, counters, yp);
             GANQ_LAUNCH_CHECK();
             return 0;
         }
     }
     if (dtype == 1)
-        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true, LW, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, M, m, n,
+        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true, LW, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, addend, M, m, n,
                            p.kb_per_wg, p.KS, partial, counters, yp);
     else
-        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false, LW, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, M, m, n,
+        hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false, LW, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, addend, M, m, n,
                            p.kb_per_wg, p.KS, partial, counters, yp);
     GANQ_LAUNCH_CHECK();
     return 0;
 }
 
 template <int BITS>
-static int launch_lut(const void* x, const uint32_t* qw, const void* lut, const void* bias, int dtype, int M, int m, int n,
+static int launch_lut(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, int dtype, int M,
+                      int m, int n,
                       const LutPlan& p, float* partial, int* counters, void* y, hipStream_t stream) {
-    if (M <= 16) return launch_lut_rt<BITS, 1>(x, qw, lut, bias, dtype, M, m, n, p, partial, counters, y, stream);
-    if (M <= 32) return launch_lut_rt<BITS, 2>(x, qw, lut, bias, dtype, M, m, n, p, partial, counters, y, stream);
-    return launch_lut_rt<BITS, 4>(x, qw, lut, bias, dtype, M, m, n, p, partial, counters, y, stream);
+    if (M <= 16) return launch_lut_rt<BITS, 1>(x, qw, lut, bias, addend, dtype, M, m, n, p, partial, counters, y, stream);
+    if (M <= 32) return launch_lut_rt<BITS, 2>(x, qw, lut, bias, addend, dtype, M, m, n, p, partial, counters, y, stream);
+    return launch_lut_rt<BITS, 4>(x, qw, lut, bias, addend, dtype, M, m, n, p, partial, counters, y, stream);
 }
 
 static int check_lut_args(const char* who, int dtype, int64_t m, int64_t n, int bits) {
@@ -441,9 +445,9 @@ static int check_lut_args(const char* who, int dtype, int64_t m, int64_t n, int 
     return 0;
 }
 
-extern "C" int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, const void* bias, int dtype,
-                                   int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace,
-                                   size_t workspace_bytes, void* stream_) {
+static int lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, const void* bias, const float* addend, int dtype,
+                          int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace, size_t workspace_bytes,
+                          void* stream_) {
     if (M < 0 || m < 0 || n < 0) return fail(-1, "ganq_lut_linear_fwd: negative shape");
     if (M == 0 || m == 0) return 0;
     int rc = check_lut_args("ganq_lut_linear_fwd", dtype, m, n, bits);
@@ -461,10 +465,23 @@ extern "C" int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const 
     float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.counter_bytes);
     const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
     ProfScope prof(KID_LUT_GEMV, stream);
-    if (bits == 2) rc = launch_lut<2>(x, qw, lut, bias, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
-    else if (bits == 3) rc = launch_lut<3>(x, qw, lut, bias, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
-    else rc = launch_lut<4>(x, qw, lut, bias, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    if (bits == 2) rc = launch_lut<2>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    else if (bits == 3) rc = launch_lut<3>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    else rc = launch_lut<4>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
     return rc;
+}
+
+extern "C" int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, const void* bias, int dtype,
+                                   int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+    return lut_linear_fwd(x, qweight, lut, bias, nullptr, dtype, M, m, n, bits, y, workspace, workspace_bytes, stream_);
+}
+
+// y = x @ dequant^T + addend + bias with addend fp32 [M, m] added before the one rounding to the activation dtype
+extern "C" int ganq_lut_linear_fwd_add(const void* x, const int32_t* qweight, const void* lut, const void* bias,
+                                       const float* addend, int dtype, int64_t M, int64_t m, int64_t n, int bits, void* y,
+                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    return lut_linear_fwd(x, qweight, lut, bias, addend, dtype, M, m, n, bits, y, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dtype, int64_t m, int64_t n, int bits,

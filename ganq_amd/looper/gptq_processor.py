@@ -72,6 +72,7 @@ class GPTQProcessor:
         self._results[module.full_name] = {
             "scale": scale, "zero": zero, "g_idx": g_idx,
             "ganq_q": g.ganq_indices, "ganq_lut": g.ganq_codebook, "bits": g.qcfg.bits,
+            "ganq_outliers": getattr(g, "ganq_outliers", None),
         }
         module.state.update({"wq": wq, "ganq_q": g.ganq_indices, "ganq_lut": g.ganq_codebook,
                              "quant_time": time.time() - t0, "avg_loss": avg_loss})
@@ -97,9 +98,11 @@ class GPTQProcessor:
             out_f = lin.weight.shape[1] if is_conv1d else lin.out_features
             q = GanqHipQuantLinear(bits=res["bits"], group_size=self.qcfg.group_size, sym=self.qcfg.sym,
                                    desc_act=self.qcfg.desc_act, in_features=in_f, out_features=out_f,
-                                   bias=lin.bias is not None, pack_dtype=self.qcfg.pack_dtype, name=full_name)
+                                   bias=lin.bias is not None, pack_dtype=self.qcfg.pack_dtype, name=full_name,
+                                   outliers=0 if res.get("ganq_outliers") is None else int(res["ganq_outliers"][1].numel()))
             q = q.to(lin.weight.device)
-            q.pack(lin, res["scale"], res["zero"], res["g_idx"], ganq_indices=res["ganq_q"], ganq_codebook=res["ganq_lut"])
+            q.pack(lin, res["scale"], res["zero"], res["g_idx"], ganq_indices=res["ganq_q"], ganq_codebook=res["ganq_lut"],
+                   ganq_outliers=res.get("ganq_outliers"))
             parent_name, _, child = full_name.rpartition(".")
             setattr(named[parent_name] if parent_name else model, child, q)
         return model

@@ -93,7 +93,7 @@ def save_quantized(model: nn.Module, path: str, qcfg: Optional[QuantizeConfig] =
         raise ValueError("save_quantized: no QuantizeConfig given and the model carries none")
     os.makedirs(path, exist_ok=True)
     modules = {n: {"bits": m.bits, "in_features": m.in_features, "out_features": m.out_features,
-                   "bias": m.bias is not None}
+                   "bias": m.bias is not None, "outliers": int(getattr(m, "outliers", 0))}
                for n, m in model.named_modules() if isinstance(m, GanqHipQuantLinear)}
     state = {k: v.detach().contiguous().cpu() for k, v in model.state_dict().items()}
     # tied weights (lm_head <-> embeddings) share storage: safetensors wants each tensor once
@@ -125,7 +125,7 @@ def load_quantized(model: nn.Module, path: str) -> nn.Module:
         lin = named[name]
         q = GanqHipQuantLinear(bits=info["bits"], group_size=qcfg.group_size, sym=qcfg.sym, desc_act=qcfg.desc_act,
                                in_features=info["in_features"], out_features=info["out_features"], bias=info["bias"],
-                               pack_dtype=torch.int32, name=name).to(lin.weight.device)
+                               pack_dtype=torch.int32, name=name, outliers=info.get("outliers", 0)).to(lin.weight.device)
         parent, _, child = name.rpartition(".")
         setattr(named[parent] if parent else model, child, q)
     state = load_file(os.path.join(path, "model.safetensors"))

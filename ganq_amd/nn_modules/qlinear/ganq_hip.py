@@ -7,6 +7,9 @@ stores the dequantised fp16 weight and runs F.linear): here the layer stores wha
   lut      fp16  [out_features, 2^bits]                    per-output-channel codebook
   bias     fp16  [out_features] (optional)
 and `forward` == `F.linear(x, lut.gather(1, Q), bias)` == FakeQuantLinear.forward on T.gather(1,Q).half().
+With the outlier split (`QuantizeConfig.ganq_outlier_ratio`, paper section 3.3) it also stores the exact outliers,
+  outlier_rowptr int32 [out_features + 1], outlier_cols int32 [nnz], outlier_vals fp16 [nnz]   (CSR by output feature)
+and `forward` == `F.linear(x, lut.gather(1, Q) + W_sparse, bias)`.
 
 `pack()` keeps the reference signature `(linear, scales, zeros, g_idx)` (utils/model.py:552-570): because that
 call only carries the dequantised nn.Linear, the indices/codebook are either passed by keyword
@@ -42,7 +45,7 @@ class GanqHipQuantLinear(BaseQuantLinear):
     QUANT_TYPE = "ganq_hip"
 
     def __init__(self, bits: int, group_size: int, sym: bool, desc_act: bool, in_features: int, out_features: int,
-                 bias: bool = False, pack_dtype: torch.dtype = torch.int32, adapter=None, **kwargs):
+                 bias: bool = False, pack_dtype: torch.dtype = torch.int32, adapter=None, outliers: int = 0, **kwargs):
         super().__init__(bits=bits, group_size=group_size, sym=sym, desc_act=desc_act, in_features=in_features,
                          out_features=out_features, bias=bias, pack_dtype=pack_dtype,
                          backend=kwargs.pop("backend", BACKEND_GANQ_HIP), adapter=adapter, **kwargs)
@@ -52,6 +55,11 @@ class GanqHipQuantLinear(BaseQuantLinear):
             self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float16))
         else:
             self.bias = None
+        self.outliers = int(outliers)  # number of stored outliers (0: plain GANQ layer, no extra buffers)
+        if self.outliers:
+            self.register_buffer("outlier_rowptr", torch.zeros(out_features + 1, dtype=torch.int32))
+            self.register_buffer("outlier_cols", torch.zeros(self.outliers, dtype=torch.int32))
+            self.register_buffer("outlier_vals", torch.zeros(self.outliers, dtype=torch.float16))
 
     def post_init(self):
         pass
@@ -75,11 +83,14 @@ class GanqHipQuantLinear(BaseQuantLinear):
         return Q, T
 
     def pack(self, linear: nn.Module, scales: torch.Tensor = None, zeros: torch.Tensor = None,
-             g_idx: torch.Tensor = None, ganq_indices: torch.Tensor = None, ganq_codebook: torch.Tensor = None):
+             g_idx: torch.Tensor = None, ganq_indices: torch.Tensor = None, ganq_codebook: torch.Tensor = None,
+             ganq_outliers=None):
         W = linear.weight.data
         if type(linear).__name__ == "Conv1D":
             W = W.t()
         dev = torch.device("cuda", torch.cuda.current_device())
+        if self.outliers and ganq_outliers is None:
+            raise ValueError("a layer with outliers cannot be recovered from its weight: pass ganq_outliers=")
         if ganq_indices is None or ganq_codebook is None:
             ganq_indices, ganq_codebook = self.codebook_from_weight(W.to(dev), self.bits)
         Q = ganq_indices.to(device=dev, dtype=torch.uint8).contiguous()
@@ -91,10 +102,26 @@ class GanqHipQuantLinear(BaseQuantLinear):
             self.bias[:] = linear.bias.to(self.bias.device, dtype=self.bias.dtype)
         else:
             assert linear.bias is None
+        if self.outliers:
+            rowptr, cols, vals = ganq_outliers
+            if cols.numel() != self.outliers or rowptr.numel() != self.out_features + 1:
+                raise ValueError("ganq_outliers do not match the layer's outlier count / out_features")
+            self.outlier_rowptr = rowptr.to(device=self.qweight.device, dtype=torch.int32).contiguous()
+            self.outlier_cols = cols.to(device=self.qweight.device, dtype=torch.int32).contiguous()
+            self.outlier_vals = vals.to(device=self.qweight.device, dtype=torch.float16).contiguous()
+
+    def _sparse_dense(self, dtype) -> torch.Tensor:
+        """W_sparse as a dense [out_features, in_features] matrix (prefill path / dequantize_weight)"""
+        Ws = torch.zeros((self.out_features, self.in_features), dtype=dtype, device=self.outlier_cols.device)
+        rows = torch.repeat_interleave(torch.arange(self.out_features, device=Ws.device),
+                                       (self.outlier_rowptr[1:] - self.outlier_rowptr[:-1]).long())
+        Ws[rows, self.outlier_cols.long()] = self.outlier_vals.to(dtype)
+        return Ws
 
     def dequantize_weight(self) -> torch.Tensor:
         """[out_features, in_features] in the lut dtype == the FakeQuantLinear weight"""
-        return _lib.lut_dequant(self.qweight, self.lut, self.in_features, self.bits)
+        Wq = _lib.lut_dequant(self.qweight, self.lut, self.in_features, self.bits)
+        return Wq + self._sparse_dense(Wq.dtype) if self.outliers else Wq
 
     def forward(self, x: torch.Tensor):
         if not x.is_cuda:
@@ -106,10 +133,16 @@ class GanqHipQuantLinear(BaseQuantLinear):
         out_shape = x.shape[:-1] + (self.out_features,)
         x2 = x.reshape(-1, self.in_features)
         if x2.shape[0] <= GEMV_MAX_ROWS:
-            y = _lib.lut_linear(x2, self.qweight, lut, bias, self.bits)
+            addend = None
+            if self.outliers:  # x @ W_sparse^T in fp32, added inside the LUT kernel before its one rounding
+                vals = self.outlier_vals if self.outlier_vals.dtype == x.dtype else self.outlier_vals.to(x.dtype)
+                addend = _lib.outlier_matmul(x2, self.outlier_rowptr, self.outlier_cols, vals, self.out_features)
+            y = _lib.lut_linear(x2, self.qweight, lut, bias, self.bits, addend=addend)
         else:
             # prefill: dequantise with the HIP kernel, then a plain library GEMM
             Wq = _lib.lut_dequant(self.qweight, lut, self.in_features, self.bits)
+            if self.outliers:
+                Wq = Wq + self._sparse_dense(Wq.dtype)
             y = torch.nn.functional.linear(x2, Wq, bias)
         return y.reshape(out_shape)
 

@@ -75,6 +75,9 @@ class QuantizeConfig:
     # "torch" runs the reference's op sequence (gptq.py:280-309) on torch.linalg.  Both are fp32 backward-stable
     # evaluations of the same quantities (they agree to ~1e-6 relative).
     ganq_prologue: str = field(default="hip", metadata={"choices": ["hip", "torch"]})
+    # not in the reference code (paper section 3.3 / Appendix A, "GANQ*"): fraction r of every weight row kept exactly
+    # as sparse fp16 outliers (row-wise, beyond the 1 - r/2 and r/2 quantiles); GANQ quantizes the rest.  0 = off.
+    ganq_outlier_ratio: float = field(default=0.0)
 
     def __post_init__(self):
         info = fields(self)
@@ -95,6 +98,8 @@ class QuantizeConfig:
                              f"is {self.quant_method}. ")
         if self.bits not in info[0].metadata["choices"]:
             raise ValueError(f"QuantizeConfig: `bits` must be in the set of `{info[0].metadata['choices']}`.")
+        if not (0.0 <= self.ganq_outlier_ratio < 1.0):
+            raise ValueError("QuantizeConfig: `ganq_outlier_ratio` must be in [0, 1)")
         if self.dynamic is not None:
             self.dynamic = {**{k: v for k, v in self.dynamic.items() if k.startswith("-")},
                             **{k: v for k, v in self.dynamic.items() if not k.startswith("-")}}

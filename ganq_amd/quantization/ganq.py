@@ -5,6 +5,10 @@ return contract `(Wq, Losses, scale: list, zero: list)`, same config fields (`bi
 Additionally keeps what the reference throws away (ganq.py:633-634,646): after `quantize()`,
 `self.ganq_indices` (uint8 [m,n], original column order) and `self.ganq_codebook` (fp32 [m,V]) hold the
 assignment and the per-row codebook that `GanqHipQuantLinear` packs.
+
+`qcfg.ganq_outlier_ratio > 0` adds the outlier split of the paper (section 3.3, Appendix A Algorithm 2; not in the
+reference code): the row-wise tails of W are taken out on the device (`_lib.outlier_split`), GANQ runs on the rest, the
+returned weight is `T.gather(1, Q) + W_sparse`, and `self.ganq_outliers` = (rowptr, cols, vals) is what the layer keeps.
 """
 import time
 
@@ -27,6 +31,7 @@ class GANQ(GPTQ):
         self.iterations = getattr(self.qcfg, "ganq_iterations", 5)
         self.ganq_indices = None
         self.ganq_codebook = None
+        self.ganq_outliers = None  # CSR (rowptr int32 [m+1], cols int32 [nnz], vals fp32 [nnz]) when the split is on
         self.ganq_stats = {}
 
     def _needs_only_hinv_diag(self) -> bool:
@@ -55,11 +60,21 @@ class GANQ(GPTQ):
             zero.append(self.quantizer.zero)
 
         t0 = time.perf_counter()
+        ratio = float(getattr(self.qcfg, "ganq_outlier_ratio", 0.0) or 0.0)
+        sparse = None
+        if ratio > 0.0:  # W becomes W_dense in place (it is this call's private fp32 copy, gptq.py:77-86)
+            rowptr, cols, vals, _ = _lib.outlier_split(W, ratio)
+            sparse = (rowptr, cols, vals)
         T0 = self._initialize_codebook_kmeans(W, Hinv, num_bits, W.device)
         assert T0.shape == (W.shape[0], V)
         alias = bool(getattr(self.qcfg, "ganq_reference_q_alias", True))
         T, Q, dists, best_k = _lib.run_layer(W, self.Xxt_damped, self.L, T0, self.iterations, alias_q=alias)
         Wq, Losses = _lib.dequant_losses(W, T, Q, _hinv_diag(Hinv).contiguous())
+        if sparse is not None:  # effective weight = dequantised dense part + the exact outliers
+            rowptr, cols, vals = sparse
+            rows = torch.repeat_interleave(torch.arange(W.shape[0], device=W.device), (rowptr[1:] - rowptr[:-1]).long())
+            Wq.index_put_((rows, cols.long()), vals, accumulate=True)
+            self.ganq_outliers = sparse
         self.ganq_indices = Q          # permuted column order until quantize() un-permutes it
         self.ganq_codebook = T
         self.ganq_stats = {"dists": dists, "best_k": best_k, "enqueue_s": time.perf_counter() - t0}
@@ -75,6 +90,14 @@ class GANQ(GPTQ):
         # T.gather(1, Q) always equals the returned weight
         if invperm is not None and self.ganq_indices is not None:
             self.ganq_indices = self.ganq_indices[:, invperm].contiguous()
+            if self.ganq_outliers is not None:  # permuted column c is original column perm[c]; keep rows ascending
+                rowptr, cols, vals = self.ganq_outliers
+                perm = torch.argsort(invperm)
+                n = invperm.numel()
+                rows = torch.repeat_interleave(torch.arange(rowptr.numel() - 1, device=cols.device),
+                                               (rowptr[1:] - rowptr[:-1]).long())
+                key, order = torch.sort(rows * n + perm[cols.long()])
+                self.ganq_outliers = (rowptr, (key % n).to(torch.int32), vals[order])
 
     def make_quantized_weight(self, Q, T):
         return T.gather(1, Q.long())

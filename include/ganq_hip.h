@@ -127,6 +127,11 @@ int ganq_lut_linear_workspace_init(void* workspace, size_t workspace_bytes, void
 int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, const void* bias, int dtype,
                         int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* same with an fp32 addend [M,m] (or NULL) added before the single rounding to the activation dtype: the sparse-outlier
+ * product of ganq_outlier_matmul */
+int ganq_lut_linear_fwd_add(const void* x, const int32_t* qweight, const void* lut, const void* bias, const float* addend,
+                            int dtype, int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace,
+                            size_t workspace_bytes, void* stream);
 /* prefill path: materialise Wq [m,n] = lut[o][index] in the activation dtype for a library GEMM */
 int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dtype, int64_t m, int64_t n, int bits, void* Wq_out,
                      void* stream);
@@ -134,6 +139,21 @@ int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dtype, int64_t
 /* pack Q [m,n] uint8 (original column order) into qweight [n*bits/32, m] int32, and back */
 int ganq_pack_indices(const uint8_t* Q, int64_t m, int64_t n, int bits, int32_t* qweight, void* stream);
 int ganq_unpack_indices(const int32_t* qweight, int64_t m, int64_t n, int bits, uint8_t* Q, void* stream);
+
+/* ---- outlier split in front of GANQ (paper section 3.3 + Appendix A Algorithm 2, paper.md:195-197,882-899; SURVEY
+ * 8(f) row 4 -- the reference repository does not implement it).  Row by row, with p = 1 - ratio/2, the entries
+ * w >= sorted[floor(n p)] or w <= sorted[ceil(n (1-p))] are outliers; they are kept exactly in a CSR matrix and zeroed
+ * in W, which GANQ then quantizes; the layer computes LUT(x) + x @ W_sparse^T.
+ *   ganq_outlier_cutoffs: cut [m,2] = (c_lower, c_upper), counts [m], rowptr [m+1] (exclusive scan; rowptr[m] = nnz).
+ *                         n <= 16384.  The caller reads rowptr[m] to size cols / vals.
+ *   ganq_outlier_extract: cols / vals [nnz] in ascending column order per row; W is overwritten by W_dense.
+ *   ganq_outlier_matmul:  out [M,m] fp32 = x [M,n] @ W_sparse^T, x and vals in `dtype` (0 = fp16, 1 = bf16).       */
+int ganq_outlier_cutoffs(const float* W, int64_t m, int64_t n, double ratio, float* cut, int32_t* counts, int32_t* rowptr,
+                         void* stream);
+int ganq_outlier_extract(float* W, int64_t m, int64_t n, const float* cut, const int32_t* rowptr, int32_t* cols, float* vals,
+                         void* stream);
+int ganq_outlier_matmul(const void* x, int dtype, int64_t M, int64_t m, int64_t n, const int32_t* rowptr, const int32_t* cols,
+                        const void* vals, float* out, void* stream);
 
 /* ---- per-kernel device timing (HIP events recorded on the caller's stream around every kernel launch) ----
  * ganq_profile_enable(1) starts collecting, ganq_profile_get() sums what has completed: the caller must have

@@ -69,3 +69,21 @@ def run_layer(W, H, L, T0, K, alias_q=True, timings=None):
             best = (d, T, Q.clone(), k)
     Q_out = Q if alias_q else best[2]
     return best[1], Q_out, dists, best[3]
+
+
+@torch.no_grad()
+def outlier_split(W: torch.Tensor, ratio: float):
+    """Outlier extraction of the paper (Appendix A, Algorithm 2; paper.md:884-899 -- the reference repository has no
+    code for it, so this restatement is pinned by the published pseudocode only: "parity unpinned").
+    W [m,n] f32 -> (W_sparse, W_dense, mask, c_lower [m], c_upper [m]); ties with a cut-off value are outliers."""
+    import math
+
+    m, n = W.shape
+    p = 1.0 - 0.5 * ratio
+    upper = min(max(int(math.floor(n * p)), 0), n - 1)
+    lower = min(max(int(math.ceil(n * (1.0 - p))), 0), n - 1)
+    srt = torch.sort(W, dim=1).values
+    c_upper, c_lower = srt[:, upper], srt[:, lower]
+    mask = (W >= c_upper[:, None]) | (W <= c_lower[:, None])
+    W_sparse = torch.where(mask, W, torch.zeros_like(W))
+    return W_sparse, W - W_sparse, mask, c_lower, c_upper

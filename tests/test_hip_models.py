@@ -77,9 +77,9 @@ def test_quantize_model_other_families(kind):
     assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=3e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize("kind", ["opt", "llama"])
+@pytest.mark.parametrize("kind,outlier_ratio", [("opt", 0.0), ("llama", 0.0), ("llama", 0.01)])
 @torch.no_grad()
-def test_quantize_model_save_load_ppl(kind, tmp_path):
+def test_quantize_model_save_load_ppl(kind, outlier_ratio, tmp_path):
     import copy
 
     from ganq_amd.models import gptq_style_ppl, load_quantized, quantize_model, save_quantized
@@ -93,14 +93,18 @@ def test_quantize_model_save_load_ppl(kind, tmp_path):
     ppl_fp = gptq_style_ppl(model, test_ids, seqlen=64)
 
     fake = copy.deepcopy(model)
-    qcfg = QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=3)
+    qcfg = QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=3,
+                          ganq_outlier_ratio=outlier_ratio)
     proc = quantize_model(model, calib, qcfg)
     n_lin = 2 * (6 if kind == "opt" else 7)
+    if outlier_ratio:  # paper section 3.3: every layer keeps its row-wise tails as sparse fp16 values
+        assert all(mod.outliers > 0 for mod in model.modules() if isinstance(mod, GanqHipQuantLinear))
     assert len(proc.results()) == n_lin and len(proc.log) == n_lin
     assert sum(isinstance(mod, GanqHipQuantLinear) for mod in model.modules()) == n_lin
 
     # the same run in the reference's FORMAT.FAKE view (dequantised weights in nn.Linear) must give the same logits
-    qcfg_fake = QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=3, format="fake")
+    qcfg_fake = QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=3, format="fake",
+                               ganq_outlier_ratio=outlier_ratio)
     quantize_model(fake, calib, qcfg_fake)
     x = test_ids[:, :64].cuda()
     a, b = model(x).logits.float(), fake(x).logits.float()

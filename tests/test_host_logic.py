@@ -20,7 +20,8 @@ def test_config_defaults_and_validation():
     q = QuantizeConfig(bits=4, quant_method="ganq")
     assert q.ganq_iterations == 5 and q.act_sort == "desc" and q.l_damp_style == "gptq" and q.dead == "zero"
     assert QuantizeConfig(desc_act=False).act_sort == "none"  # config.py:275-276
-    for bad in (dict(bits=5), dict(damp_percent=1.5), dict(format="gptq"), dict(group_size=0), dict(pack_dtype="fp8")):
+    for bad in (dict(bits=5), dict(damp_percent=1.5), dict(format="gptq"), dict(group_size=0), dict(pack_dtype="fp8"),
+                dict(ganq_outlier_ratio=1.0), dict(ganq_outlier_ratio=-0.1)):
         with pytest.raises(ValueError):
             QuantizeConfig(**bad)
     q = QuantizeConfig(dynamic={r"-:.*\.k_proj": {}, r".*\.fc1": {"bits": 3}})
@@ -28,6 +29,25 @@ def test_config_defaults_and_validation():
     assert q.dynamic_get("model.layers.0.fc1", "bits", 4) == 3
     assert q.dynamic_get("model.layers.0.fc2", "bits", 4) == 4
     assert QuantizeConfig.from_dict(q.to_dict()).dynamic == q.dynamic
+    assert q.ganq_outlier_ratio == 0.0  # the outlier split of the paper is opt-in
+    assert QuantizeConfig.from_dict(QuantizeConfig(ganq_outlier_ratio=0.005).to_dict()).ganq_outlier_ratio == 0.005
+
+
+def test_outlier_split_restatement():
+    """oracle restatement of the paper's Algorithm 2 (Appendix A): cut-off positions, symmetric tails, W = sparse + dense"""
+    from oracle import ganq_ref
+
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(40, 2000, generator=g)
+    Ws, Wd, mask, c_lo, c_hi = ganq_ref.outlier_split(W, 0.01)
+    assert torch.equal(Ws + Wd, W) and torch.equal(Wd[mask], torch.zeros(int(mask.sum())))
+    srt = torch.sort(W, dim=1).values
+    # floor(2000 * 0.995) = 1990; ceil(2000 * (1 - 0.995)) = 11 in double arithmetic (1 - 0.995 = 0.005000000000000004)
+    assert torch.equal(c_hi, srt[:, 1990]) and torch.equal(c_lo, srt[:, 11])
+    assert torch.equal(mask.sum(1), torch.full((40,), 10 + 12))  # >= sorted[1990]: 10 entries, <= sorted[11]: 12
+    W[3, :1500] = 0.25  # ties with a cut-off all count
+    _, _, mask, c_lo, _ = ganq_ref.outlier_split(W, 0.01)
+    assert int(mask[3].sum()) >= 22
 
 
 def test_quantlinear_validate_falls_through():
