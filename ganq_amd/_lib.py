@@ -67,6 +67,7 @@ SIGNATURES = {
     "ganq_unpack_indices": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
     "ganq_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "ganq_profile_reset": (ctypes.c_int, []),
+    "ganq_profile_select": (ctypes.c_int, [ctypes.c_int]),
     "ganq_profile_num_kernels": (ctypes.c_int, []),
     "ganq_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
     "ganq_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)]),
@@ -257,8 +258,15 @@ def run_layer(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None):
     return T, Q, dists[:K], best_k
 
 
-def profile_enable(on: bool = True):
+def profile_enable(on: bool = True, only: str = None):
+    """HIP-event timing of the library's kernels; `only`: instrument just this kernel (the events of a fully
+    instrumented run leave idle gaps between the dependent launches)."""
     lib().ganq_profile_reset()
+    kid = -1
+    if only is not None:
+        names = [lib().ganq_profile_kernel_name(i).decode() for i in range(lib().ganq_profile_num_kernels())]
+        kid = names.index(only)
+    lib().ganq_profile_select(kid)
     lib().ganq_profile_enable(1 if on else 0)
 
 

@@ -64,13 +64,13 @@ enum KernelId : int {
     KID_CHOLESKY,
     KID_COUNT
 };
-bool profile_enabled();
+bool profile_enabled(int kid);
 void profile_mark(int kid, hipStream_t stream, bool begin);
 struct ProfScope {
     int kid;
     hipStream_t stream;
     bool on;
-    ProfScope(int k, hipStream_t s) : kid(k), stream(s), on(profile_enabled()) {
+    ProfScope(int k, hipStream_t s) : kid(k), stream(s), on(profile_enabled(k)) {
         if (on) profile_mark(kid, stream, true);
     }
     ~ProfScope() {

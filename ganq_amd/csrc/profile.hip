@@ -17,10 +17,11 @@ struct Span {
 };
 static std::mutex g_mu;
 static bool g_on = false;
+static int g_sel = -1;  // -1: every kernel, else only this kernel id (events between dependent launches cost idle time)
 static std::vector<Span> g_spans;
 static std::vector<hipEvent_t> g_pool;
 
-bool profile_enabled() { return g_on; }
+bool profile_enabled(int kid) { return g_on && (g_sel < 0 || g_sel == kid); }
 
 static hipEvent_t get_event() {
     if (!g_pool.empty()) {
@@ -56,6 +57,12 @@ using namespace ganq;
 extern "C" int ganq_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_mu);
     g_on = on != 0;
+    return 0;
+}
+
+extern "C" int ganq_profile_select(int kernel_id) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_sel = (kernel_id >= 0 && kernel_id < KID_COUNT) ? kernel_id : -1;
     return 0;
 }
 

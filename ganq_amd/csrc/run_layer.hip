@@ -11,21 +11,38 @@
 namespace ganq {
 
 __global__ void best_init_kernel(double* best, int32_t* best_k, int32_t* flag) {
-    *best = INFINITY;
+    best[0] = INFINITY;  // best[k & 1] is read by iteration k, best[(k + 1) & 1] written
     *best_k = -1;
     *flag = 0;
 }
 
-// ganq.py:625-626   if curr_dist < best: best = (curr_dist, T, Q)   (strict <, NaN never wins)
-__global__ void best_select_kernel(const double* dist, int k, double* best, int32_t* best_k, int32_t* flag) {
-    const double d = *dist;
-    if (d < *best) {
-        *best = d;
-        *best_k = k;
-        *flag = 1;
-    } else {
-        *flag = 0;
+// ganq.py:621-626 in one launch: dist = sum of the per-row losses (fixed order), if dist < best: best = (dist, T)
+// (strict <, NaN never wins).  Every workgroup forms the same sum and takes the same decision; the running best is
+// double-buffered (read [k & 1], write [(k + 1) & 1]) so that no workgroup can see this launch's update.
+__global__ __launch_bounds__(256) void select_copy_kernel(const double* __restrict__ loss_rows, int m, int k, double* best,
+                                                          int32_t* best_k, int32_t* flag, double* __restrict__ dists,
+                                                          const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                          int64_t words) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < m; i += 256) s += loss_rows[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
     }
+    const double d = sh[0], b = best[k & 1];
+    const bool win = d < b;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        dists[k] = d;
+        best[(k + 1) & 1] = win ? d : b;
+        if (win) *best_k = k;
+        *flag = win ? 1 : 0;
+    }
+    if (!win) return;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void copy_if_kernel(const int32_t* __restrict__ flag, const uint32_t* __restrict__ src,
@@ -78,7 +95,7 @@ static RunLayout run_layout(int64_t m, int64_t n, int V) {
     lo.off_q = take((size_t)m * n);
     lo.off_solve = take(lo.solve_bytes);
     lo.off_upd = take(lo.t.total);
-    lo.off_best = take(sizeof(double));
+    lo.off_best = take(2 * sizeof(double));
     lo.off_flag = take(sizeof(int32_t));
     lo.total = off;
     return lo;
@@ -132,13 +149,17 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
         rc = solve_s_launch(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, stream);
         if (rc) return rc;
         // new codebook and, from the same A and b, the loss of (new codebook, these indices)  (ganq.py:589-591, :621-622)
-        rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, dists + k, k, stream);
+        rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, 1, nullptr, k, stream);
         if (rc) return rc;
         std::swap(Tc, Tn);
-        hipLaunchKernelGGL(best_select_kernel, dim3(1), dim3(1), 0, stream, dists + k, k, best, best_k, flag);
-        GANQ_LAUNCH_CHECK();
-        rc = launch_copy_if(flag, Tc, T_best, (size_t)m * V * sizeof(float), stream);
-        if (rc) return rc;
+        {
+            const int64_t words = m * V;  // fp32 codebook
+            const int blocks = (int)std::min<int64_t>(64, std::max<int64_t>(1, (words + 255) / 256));
+            hipLaunchKernelGGL(select_copy_kernel, dim3(blocks), dim3(256), 0, stream, t_loss_rows(lo.t, ws + lo.off_upd), (int)m, k,
+                               best, best_k, flag, dists, reinterpret_cast<const uint32_t*>(Tc), reinterpret_cast<uint32_t*>(T_best),
+                               words);
+            GANQ_LAUNCH_CHECK();
+        }
         if (!alias) {
             if (k == 0) {  // defined contents even if no iteration ever wins (all distances NaN)
                 GANQ_HIP_CHECK(hipMemcpyAsync(Q_out, Qwork, (size_t)m * n, hipMemcpyDeviceToDevice, stream));

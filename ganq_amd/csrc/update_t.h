@@ -21,11 +21,14 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
               hipStream_t stream);
 
 // once per iteration.  WH32 != nullptr: b from the caller's fp32 W@H (stage API, no loss);
-// WH32 == nullptr: b from the fp64 product prepared by t_prepare, loss_out (device double) optional.
+// WH32 == nullptr: b from the product prepared by t_prepare; loss_mode 0: no loss, 1: per-row losses only
+// (t_loss_rows; the caller reduces them), 2: also their sum in loss_out (device double).
 // iter < 0: stateless (full accumulation).  iter >= 0 (layout built with with_f64): the bucket sums are kept between
 // calls; iter == 0 accumulates them in full, later calls only move the H entries of the indices that changed
 // (exact: the sums are integers), falling back to the full accumulation on the device when too many changed.
 int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
-              float* T_out, float* A_out, float* b_out, double* loss_out, int iter, hipStream_t stream);
+              float* T_out, float* A_out, float* b_out, int loss_mode, double* loss_out, int iter, hipStream_t stream);
+
+inline const double* t_loss_rows(const TLayout& lo, const char* ws) { return reinterpret_cast<const double*>(ws + lo.off_lossrows); }
 
 }  // namespace ganq

@@ -509,7 +509,11 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
                                                      const double* __restrict__ wHw, const uint8_t* __restrict__ Q, int m,
                                                      int n, int V, double rcond, float* __restrict__ T_out,
                                                      float* __restrict__ A_out, float* __restrict__ b_out,
-                                                     double* __restrict__ loss_rows, int nparts) {
+                                                     double* __restrict__ loss_rows, int nparts,
+                                                     long long* __restrict__ changed_reset) {
+    // the change counter of this iteration has been consumed by the kernels in front of this one: leave it zero for
+    // the next iteration's q_diff_kernel (saves a memset launch per iteration)
+    if (changed_reset && blockIdx.x == 0 && threadIdx.x == 0) *changed_reset = 0;
     __shared__ double As[4][16][JS];
     __shared__ double Es[4][16][JS];
     __shared__ double A0[4][16][JS];       // unrounded A (for the loss), also scratch for the bucket sums
@@ -901,6 +905,8 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
                        planes, hdiag, H64, Hint);
     GANQ_LAUNCH_CHECK();
     if (with_f64) {
+        // change counter of the incremental bucket sums: zero once, every t_solve leaves it zero again
+        GANQ_HIP_CHECK(hipMemsetAsync(ws + lo.off_chgcnt + align_up((size_t)m * sizeof(int), 8), 0, sizeof(long long), stream));
         double* WH64 = reinterpret_cast<double*>(ws + lo.off_wh64);
         double* wHw = reinterpret_cast<double*>(ws + lo.off_whw);
         const int tiles = (int)(((m + DM - 1) / DM) * ((n + DN - 1) / DN));
@@ -920,7 +926,7 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
 
 // per iteration: bucket sums (full: masks -> integer accumulation; or incremental) -> per-row solve (+ loss rows)
 int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
-              float* T_out, float* A_out, float* b_out, double* loss_out, int iter, hipStream_t stream) {
+              float* T_out, float* A_out, float* b_out, int loss_mode, double* loss_out, int iter, hipStream_t stream) {
     TPrep* prep = reinterpret_cast<TPrep*>(ws + lo.off_prep);
     int8_t* planes = reinterpret_cast<int8_t*>(ws + lo.off_planes);
     int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
@@ -941,7 +947,6 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
     if (stateful && iter > 0) {
         ProfScope prof(KID_T_INCR, stream);
         uint16_t* chg = reinterpret_cast<uint16_t*>(ws + lo.off_chg);
-        GANQ_HIP_CHECK(hipMemsetAsync(changed, 0, sizeof(long long), stream));
         hipLaunchKernelGGL(q_diff_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, Q, qprev, (int)m, (int)n, chg, chgcnt,
                            changed);
         const size_t usmem = (size_t)(256 + MU_WAVES * 16 * 64) * sizeof(long long) + align_up((size_t)n, 16);
@@ -998,14 +1003,14 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         if (WH32) {
             hipLaunchKernelGGL(t_solve_kernel<float>, grid, dim3(64), 0, stream, msrc, prep, hdiag, WH32,
                                static_cast<const double*>(nullptr), Q, (int)m, (int)n, V, rcond, T_out, A_out, b_out,
-                               static_cast<double*>(nullptr), nparts);
+                               static_cast<double*>(nullptr), nparts, static_cast<long long*>(nullptr));
         } else {
             const double* WH64 = reinterpret_cast<const double*>(ws + lo.off_wh64);
             const double* wHw = reinterpret_cast<const double*>(ws + lo.off_whw);
             double* loss_rows = reinterpret_cast<double*>(ws + lo.off_lossrows);
             hipLaunchKernelGGL(t_solve_kernel<double>, grid, dim3(64), 0, stream, msrc, prep, hdiag, WH64, wHw, Q, (int)m,
-                               (int)n, V, rcond, T_out, A_out, b_out, loss_out ? loss_rows : nullptr, nparts);
-            if (loss_out) hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, loss_rows, (int)m, loss_out);
+                               (int)n, V, rcond, T_out, A_out, b_out, loss_mode ? loss_rows : nullptr, nparts, changed);
+            if (loss_mode == 2) hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, loss_rows, (int)m, loss_out);
         }
     }
     GANQ_LAUNCH_CHECK();
@@ -1062,5 +1067,5 @@ extern "C" int ganq_update_t(const float* WH, const float* H, const uint8_t* Q, 
     char* ws = static_cast<char*>(workspace);
     int rc = t_prepare(nullptr, H, m, n, lo, ws, false, stream);
     if (rc) return rc;
-    return t_iterate(Q, m, n, V, rcond, lo, ws, WH, T_out, A_out, b_out, nullptr, -1, stream);
+    return t_iterate(Q, m, n, V, rcond, lo, ws, WH, T_out, A_out, b_out, 0, nullptr, -1, stream);
 }
