@@ -503,6 +503,158 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
     for (int e = tid; e < cnt; e += MU_WAVES * 64) qp[list[e]] = qn[list[e]];
 }
 
+// The same move on the integer matrix cores (rows whose length is a multiple of 16).  The 16-bucket histograms of the
+// changed columns of one row are one small GEMM:  S[b][e] = sum_x [old[x] == b] * Hint[c_e][x]  =  onehot(old codes)
+// [16 x n]  @  digits of the rows c_e of H [n x changes], with the 4 int8 digit planes t_prepare already holds
+// (v_mfma_i32_16x16x64_i8, 16 changes per tile, up to 2 tiles per pass).  It is formed with the OLD codes everywhere;
+// what the list-order semantics of m_update_kernel adds -- the changed column itself is left out, earlier changes of
+// the row already carry their new code -- are cnt diagonal entries and cnt^2/2 single entries of Hint, applied to F
+// directly.  One workgroup per row whose 4 waves split the columns (a row is a chain of dependent memory round
+// trips; partial sums simply add into F, they are integers); the A operand (one-hot bytes) is built from 16 code bytes per lane with a zero-byte
+// test, the B operand is 16 contiguous digit bytes of a changed column's row.  All sums are integers: the result is
+// bit-identical to m_update_kernel and to the full accumulation.
+constexpr int MG_TILES = 2;   // 32 changes per pass over the row (p99 of the benchmark layer's first update: 28)
+constexpr int MG_WAVES = 4;   // the waves of a row's workgroup split the columns
+
+__device__ __forceinline__ uint32_t bytes_equal(uint32_t x, uint32_t pat) {  // 0x01 in every byte of x equal to pat's
+    const uint32_t y = x ^ pat;
+    const uint32_t t = ((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y;
+    return (~t & 0x80808080u) >> 7;
+}
+
+template <int NT>
+__device__ __forceinline__ void mu_group(const int8_t* __restrict__ planes, int n, int nq, const uint8_t* __restrict__ qp,
+                                         const int (&cj)[MG_TILES], int lane, int kb, int ke, v4i (&acc)[MG_TILES][4]) {
+    const int i16 = lane & 15, kq = lane >> 4;
+    const uint32_t pat = (uint32_t)i16 * 0x01010101u;
+    const int64_t plane = (int64_t)n * nq;
+    const int8_t* bp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bp[t] = planes + (int64_t)cj[t] * nq + 16 * kq;
+    if (kb >= ke) return;
+    auto load = [&](int k0, uint4& cw, v4i (&bf)[NT][4]) {
+        cw = *reinterpret_cast<const uint4*>(qp + min(k0 + 16 * kq, n - 16));  // past n the digits are zero
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) bf[t][p] = *reinterpret_cast<const v4i*>(bp[t] + p * plane + k0);
+    };
+    // every step is one dependent round trip to L2 / Infinity Cache: D steps of operands are kept in flight
+    constexpr int D = NT == 1 ? 4 : 2;
+    uint4 cw[D];
+    v4i bf[D][NT][4];
+    auto step = [&](const uint4& c, const v4i (&b)[NT][4]) {
+        v4i af;
+        af[0] = (int)bytes_equal(c.x, pat);
+        af[1] = (int)bytes_equal(c.y, pat);
+        af[2] = (int)bytes_equal(c.z, pat);
+        af[3] = (int)bytes_equal(c.w, pat);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[t][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, b[t][p], acc[t][p], 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(min(kb + 64 * d, ke - 64), cw[d], bf[d]);
+    for (int k0 = kb; k0 < ke; k0 += 64 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (k0 + 64 * d < ke) step(cw[d], bf[d]);                    // uniform
+            load(min(k0 + 64 * (d + D), ke - 64), cw[d], bf[d]);        // clamped: the tail re-reads its last step
+        }
+    }
+}
+
+__global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8_t* __restrict__ planes, const int* __restrict__ Hint,
+                                                           const int* __restrict__ hdiag_int, const uint8_t* __restrict__ Q,
+                                                           uint8_t* __restrict__ Qprev, int m, int n, int nq,
+                                                           const uint16_t* __restrict__ chg, const int* __restrict__ chgcnt,
+                                                           long long* __restrict__ Mstate, const long long* __restrict__ changed,
+                                                           long long thr) {
+    if (*changed > thr) return;  // the full accumulation runs instead
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cnt = chgcnt[row];
+    if (cnt == 0) return;
+    __shared__ long long Frow[256];
+    long long* Fg = Mstate + (int64_t)row * 256;
+    uint8_t* qp = Qprev + (int64_t)row * n;
+    const uint8_t* qn = Q + (int64_t)row * n;
+    const uint16_t* list = chg + (int64_t)row * n;
+    Frow[tid] = Fg[tid];
+    // the row's changes (column, old code, new code): one parallel round of loads instead of dependent ones per use
+    constexpr int CAP = 512;
+    __shared__ uint16_t s_col[CAP];
+    __shared__ uint8_t s_old[CAP], s_new[CAP];
+    for (int e = tid; e < min(cnt, CAP); e += MG_WAVES * 64) {
+        const int c = list[e];
+        s_col[e] = (uint16_t)c;
+        s_old[e] = (uint8_t)min((int)qp[c], 15);
+        s_new[e] = (uint8_t)min((int)qn[c], 15);
+    }
+    __syncthreads();
+    auto col_of = [&](int e) -> int { return e < CAP ? (int)s_col[e] : (int)list[e]; };
+    auto old_of = [&](int e) -> int { return e < CAP ? (int)s_old[e] : min((int)qp[list[e]], 15); };
+    auto new_of = [&](int e) -> int { return e < CAP ? (int)s_new[e] : min((int)qn[list[e]], 15); };
+    const int ksteps = (n + 63) >> 6, kper = (ksteps + MG_WAVES - 1) / MG_WAVES;
+    const int kb = min(wv * kper, ksteps) * 64, ke = min((wv + 1) * kper, ksteps) * 64;  // this wave's columns
+    auto lds_add = [&](long long* p, long long v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    // F[a_old][b] -= s, F[b][a_old] -= s, F[a_new][b] += s, F[b][a_new] += s
+    auto move = [&](int a_old, int a_new, int b, long long s) {
+        lds_add(&Frow[a_old * 16 + b], -s);
+        lds_add(&Frow[b * 16 + a_old], -s);
+        lds_add(&Frow[a_new * 16 + b], s);
+        lds_add(&Frow[b * 16 + a_new], s);
+    };
+    const int i16 = lane & 15, kq = lane >> 4;
+    for (int g0 = 0; g0 < cnt; g0 += 16 * MG_TILES) {
+        const int nt = min(MG_TILES, (cnt - g0 + 15) >> 4);
+        int cj[MG_TILES];
+#pragma unroll
+        for (int t = 0; t < MG_TILES; ++t) {
+            const int e = g0 + 16 * t + i16;
+            cj[t] = col_of(e < cnt ? e : g0);  // padding columns repeat a valid one; their sums are dropped below
+        }
+        v4i acc[MG_TILES][4];
+#pragma unroll
+        for (int t = 0; t < MG_TILES; ++t)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[t][p] = v4i{0, 0, 0, 0};
+        if (nt == 1) mu_group<1>(planes, n, nq, qp, cj, lane, kb, ke, acc);
+        else mu_group<2>(planes, n, nq, qp, cj, lane, kb, ke, acc);
+        // D layout: lane (j = lane & 15, kq) holds S[b = 4 kq + r][change j], r = 0..3
+#pragma unroll
+        for (int t = 0; t < MG_TILES; ++t) {
+            const int e = g0 + 16 * t + i16;
+            if (t < nt && e < cnt) {
+                const int a_old = old_of(e), a_new = new_of(e);
+                const long long self = wv == 0 ? (long long)hdiag_int[cj[t]] : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = 4 * kq + r;
+                    long long sb = (long long)acc[t][0][r] + ((long long)acc[t][1][r] << 8) + ((long long)acc[t][2][r] << 16) +
+                                   ((long long)acc[t][3][r] << 24);
+                    if (b == a_old) sb -= self;  // the column itself is not part of its own histogram (taken out once)
+                    if (sb != 0) move(a_old, a_new, b, sb);
+                }
+            }
+        }
+    }
+    // earlier changes e' < e of the row already carry their new code when change e is applied: all pairs at once
+    for (int64_t pidx = tid; pidx < (int64_t)cnt * cnt; pidx += MG_WAVES * 64) {
+        const int e = (int)(pidx / cnt), e2 = (int)(pidx - (int64_t)e * cnt);
+        if (e2 >= e) continue;
+        const long long v = (long long)Hint[(int64_t)col_of(e) * n + col_of(e2)];
+        if (v != 0) {
+            const int a_old = old_of(e), a_new = new_of(e);
+            move(a_old, a_new, new_of(e2), v);
+            move(a_old, a_new, old_of(e2), -v);
+        }
+    }
+    __syncthreads();
+    Fg[tid] = Frow[tid];
+    for (int e = tid; e < cnt; e += MG_WAVES * 64) qp[list[e]] = qn[list[e]];
+}
+
 template <typename WHT>
 __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict__ Mpart, const TPrep* __restrict__ prep,
                                                      const int* __restrict__ hdiag_int, const WHT* __restrict__ WH,
@@ -956,9 +1108,15 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)usmem));
             attr_usmem = usmem;
         }
-        hipLaunchKernelGGL(m_update_kernel, dim3((unsigned)m), dim3(MU_WAVES * 64), usmem, stream,
-                           reinterpret_cast<const int*>(ws + lo.off_hint), Q, qprev, (int)m, (int)n, chg, chgcnt, mstate, changed,
-                           thr);
+        static const bool mu_lds = [] { const char* e = getenv("GANQ_MUPDATE_LDS"); return e && e[0] == '1'; }();  // A/B hook
+        if ((n & 15) == 0 && !mu_lds)
+            hipLaunchKernelGGL(m_update_mfma_kernel, dim3((unsigned)m), dim3(MG_WAVES * 64), 0, stream, planes,
+                               reinterpret_cast<const int*>(ws + lo.off_hint), hdiag, Q, qprev, (int)m, (int)n, (int)lo.nq, chg,
+                               chgcnt, mstate, changed, thr);
+        else
+            hipLaunchKernelGGL(m_update_kernel, dim3((unsigned)m), dim3(MU_WAVES * 64), usmem, stream,
+                               reinterpret_cast<const int*>(ws + lo.off_hint), Q, qprev, (int)m, (int)n, chg, chgcnt, mstate,
+                               changed, thr);
         GANQ_LAUNCH_CHECK();
         gate = changed;
     }

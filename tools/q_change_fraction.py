@@ -18,6 +18,9 @@ for k in range(10):
     if Qp is not None:
         ch = (Q != Qp)
         per_row = ch.float().mean(dim=1)
-        print(f"iter {k}: changed {ch.float().mean().item() * 100:6.2f}% of indices; rows: median {per_row.median().item() * 100:.2f}% max {per_row.max().item() * 100:.2f}%", flush=True)
+        cnt = ch.sum(dim=1).float()
+        qs = torch.quantile(cnt, torch.tensor([0.5, 0.9, 0.99, 0.999], device=cnt.device)).tolist()
+        print(f"iter {k}: changed {ch.float().mean().item() * 100:6.2f}% of indices; rows: median {per_row.median().item() * 100:.2f}% max {per_row.max().item() * 100:.2f}%;"
+              f" changes per row: p50 {qs[0]:.0f} p90 {qs[1]:.0f} p99 {qs[2]:.0f} p99.9 {qs[3]:.0f} max {cnt.max().item():.0f} (rows with > 64: {(cnt > 64).sum().item()})", flush=True)
     Qp = Q
     T = _lib.update_t(WH, H, Q, V)
