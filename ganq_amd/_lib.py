@@ -16,7 +16,7 @@ import threading
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libganq_hip.so")
+LIB_PATH = os.environ.get("GANQ_HIP_LIB") or os.path.join(_PKG_DIR, "libganq_hip.so")  # override: developer builds
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 
 FLAG_ALIAS_Q = 1

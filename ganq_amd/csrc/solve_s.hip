@@ -222,11 +222,13 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
 #pragma unroll
                     for (int k = 0; k < 4; ++k) wnext[k] = W[(int64_t)prow * n + j0 - SB + c16 + 16 * k];  // full panel
                 }
+#ifndef GANQ_SOLVE_NO_P  // timing experiment: results are meaningless without the panel steps
                 if (wd == SB) {
                     panel_all<true>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
                 } else {
                     panel_all<false>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
                 }
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int col = c16 + 16 * k;
@@ -331,8 +333,10 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                 }
             };
             const int plds = max(bG + 2, pbase);  // lowest source panel of this chain whose Err block lives in LDS
+#ifndef GANQ_SOLVE_NO_G  // timing experiment: results are meaningless without the residual chain
             chain(std::true_type{}, nb - 1, plds);
             chain(std::false_type{}, min(nb - 1, plds - 1), bG + 2);
+#endif
 #pragma unroll
             for (int e = 0; e < (SB * SB) / 256; ++e) {
                 const int idx = e * 256 + gtid;

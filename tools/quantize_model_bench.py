@@ -61,10 +61,13 @@ def main():
     ppl_q = gptq_style_ppl(model, test_ids, a.seqlen)
     quant_s = sum(float(r["time"]) for r in proc.log)
     cols = sum(m.in_features for m in model.modules() if type(m).__name__ == "GanqHipQuantLinear")
+    by_name = {}
+    for r in proc.log:
+        by_name[r["module"]] = by_name.get(r["module"], 0.0) + float(r["time"])
     print(json.dumps({"arch": a.arch, "layers": cfg.num_hidden_layers, "modules": len(proc.log), "bits": a.bits,
                       "ganq_iterations": a.iters, "calibration": f"{a.nsamples}x{a.seqlen} synthetic tokens",
                       "total_s": round(dt, 3), "sum_module_quantize_s": round(quant_s, 3),
-                      "weight_columns": cols, "columns_per_s_whole_run": round(cols / dt, 1),
+                      "quantize_s_by_module": {k: round(v, 3) for k, v in by_name.items()}, "weight_columns": cols, "columns_per_s_whole_run": round(cols / dt, 1),
                       "ppl_random_init_fp16": round(ppl_fp, 2), "ppl_random_init_ganq": round(ppl_q, 2)}))
 
 
