@@ -59,6 +59,9 @@ SIGNATURES = {
                                            ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_lut_linear_fwd_add": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64,
                                                ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ganq_lut_linear_outliers_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, ctypes.c_int]),
+    "ganq_lut_linear_fwd_outliers": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64,
+                                                    _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_lut_dequant": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
     "ganq_outlier_cutoffs": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp]),
     "ganq_outlier_extract": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
@@ -420,6 +423,25 @@ def outlier_matmul(x, rowptr, cols, vals, m: int):
     _check(lib().ganq_outlier_matmul(x.data_ptr(), code, M, m, n, rowptr.data_ptr(), _ptr(cols) if cols.numel() else None,
                                      _ptr(vals) if vals.numel() else None, out.data_ptr(), _stream()), "ganq_outlier_matmul")
     return out
+
+
+def lut_linear_outliers(x, qweight, lut, bias, bits: int, rowptr, cols, vals):
+    """LUT forward of a layer with sparse outliers (CSR by output feature, vals in x's dtype) in one library call."""
+    code = _act_dtype(x, "x")
+    if lut.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype) or vals.dtype != x.dtype:
+        raise GanqHipError("x, lut, bias and outlier values must share one dtype")
+    if rowptr.dtype != torch.int32 or cols.dtype != torch.int32 or rowptr.numel() != lut.shape[0] + 1:
+        raise GanqHipError("lut_linear_outliers: rowptr / cols must be int32, rowptr of length out_features + 1")
+    x, qweight, lut = x.contiguous(), qweight.contiguous(), lut.contiguous()
+    M, n = x.shape
+    m = lut.shape[0]
+    y = torch.empty((M, m), dtype=x.dtype, device=x.device)
+    ws = _lut_workspace(lib().ganq_lut_linear_outliers_workspace_bytes(M, m, n, bits), x.device)
+    _check(lib().ganq_lut_linear_fwd_outliers(x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), rowptr.data_ptr(),
+                                              cols.data_ptr() if cols.numel() else None,
+                                              vals.data_ptr() if vals.numel() else None, code, M, m, n, bits, y.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _stream()), "ganq_lut_linear_fwd_outliers")
+    return y
 
 
 def lut_linear(x, qweight, lut, bias, bits: int, addend=None):

@@ -484,6 +484,32 @@ extern "C" int ganq_lut_linear_fwd_add(const void* x, const int32_t* qweight, co
     return lut_linear_fwd(x, qweight, lut, bias, addend, dtype, M, m, n, bits, y, workspace, workspace_bytes, stream_);
 }
 
+// LUT forward of a layer with sparse outliers in one call: the sparse product goes to the tail of the workspace as fp32
+// and is added by the LUT kernel before its rounding (two launches, no host work in between)
+extern "C" int ganq_outlier_matmul(const void* x, int dtype, int64_t M, int64_t m, int64_t n, const int32_t* rowptr,
+                                   const int32_t* cols, const void* vals, float* out, void* stream_);
+
+extern "C" size_t ganq_lut_linear_outliers_workspace_bytes(int64_t M, int64_t m, int64_t n, int bits) {
+    if (M <= 0 || m <= 0) return 0;
+    return align_up(ganq_lut_linear_workspace_bytes(M, m, n, bits), 256) + (size_t)M * m * sizeof(float);
+}
+
+extern "C" int ganq_lut_linear_fwd_outliers(const void* x, const int32_t* qweight, const void* lut, const void* bias,
+                                            const int32_t* rowptr, const int32_t* cols, const void* vals, int dtype, int64_t M,
+                                            int64_t m, int64_t n, int bits, void* y, void* workspace, size_t workspace_bytes,
+                                            void* stream_) {
+    if (M < 0 || m < 0 || n < 0) return fail(-1, "ganq_lut_linear_fwd_outliers: negative shape");
+    if (M == 0 || m == 0) return 0;
+    const size_t base = align_up(ganq_lut_linear_workspace_bytes(M, m, n, bits), 256);
+    if (!workspace || workspace_bytes < base + (size_t)M * m * sizeof(float))
+        return fail(-4, "ganq_lut_linear_fwd_outliers: workspace %zu B < required %zu B", workspace_bytes,
+                    base + (size_t)M * m * sizeof(float));
+    float* addend = reinterpret_cast<float*>(static_cast<char*>(workspace) + base);
+    int rc = ganq_outlier_matmul(x, dtype, M, m, n, rowptr, cols, vals, addend, stream_);
+    if (rc) return rc;
+    return lut_linear_fwd(x, qweight, lut, bias, addend, dtype, M, m, n, bits, y, workspace, base, stream_);
+}
+
 extern "C" int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dtype, int64_t m, int64_t n, int bits,
                                 void* Wq_out, void* stream_) {
     if (m < 0 || n < 0) return fail(-1, "ganq_lut_dequant: negative shape");

@@ -133,11 +133,11 @@ class GanqHipQuantLinear(BaseQuantLinear):
         out_shape = x.shape[:-1] + (self.out_features,)
         x2 = x.reshape(-1, self.in_features)
         if x2.shape[0] <= GEMV_MAX_ROWS:
-            addend = None
             if self.outliers:  # x @ W_sparse^T in fp32, added inside the LUT kernel before its one rounding
                 vals = self.outlier_vals if self.outlier_vals.dtype == x.dtype else self.outlier_vals.to(x.dtype)
-                addend = _lib.outlier_matmul(x2, self.outlier_rowptr, self.outlier_cols, vals, self.out_features)
-            y = _lib.lut_linear(x2, self.qweight, lut, bias, self.bits, addend=addend)
+                y = _lib.lut_linear_outliers(x2, self.qweight, lut, bias, self.bits, self.outlier_rowptr, self.outlier_cols, vals)
+            else:
+                y = _lib.lut_linear(x2, self.qweight, lut, bias, self.bits)
         else:
             # prefill: dequantise with the HIP kernel, then a plain library GEMM
             Wq = _lib.lut_dequant(self.qweight, lut, self.in_features, self.bits)

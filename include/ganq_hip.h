@@ -132,6 +132,12 @@ int ganq_lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, 
 int ganq_lut_linear_fwd_add(const void* x, const int32_t* qweight, const void* lut, const void* bias, const float* addend,
                             int dtype, int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* both in one call for a layer with outliers (ganq_outlier_matmul into the tail of the workspace, then the LUT kernel);
+ * the workspace is initialised like the plain one (ganq_lut_linear_workspace_init over all of it) */
+size_t ganq_lut_linear_outliers_workspace_bytes(int64_t M, int64_t m, int64_t n, int bits);
+int ganq_lut_linear_fwd_outliers(const void* x, const int32_t* qweight, const void* lut, const void* bias,
+                                 const int32_t* rowptr, const int32_t* cols, const void* vals, int dtype, int64_t M, int64_t m,
+                                 int64_t n, int bits, void* y, void* workspace, size_t workspace_bytes, void* stream);
 /* prefill path: materialise Wq [m,n] = lut[o][index] in the activation dtype for a library GEMM */
 int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dtype, int64_t m, int64_t n, int bits, void* Wq_out,
                      void* stream);

@@ -29,5 +29,6 @@ for M in (1, 4, 16, 64):
     t_plain = timeit(lambda: _lib.lut_linear(x, qw, lut, None, bits))
     t_sp = timeit(lambda: _lib.outlier_matmul(x, rowptr, cols, vh, m))
     t_both = timeit(lambda: _lib.lut_linear(x, qw, lut, None, bits, addend=_lib.outlier_matmul(x, rowptr, cols, vh, m)))
+    t_one = timeit(lambda: _lib.lut_linear_outliers(x, qw, lut, None, bits, rowptr, cols, vh))
     t_fp = timeit(lambda: torch.nn.functional.linear(x, Wd))
-    print(f"M={M}: LUT {t_plain:.1f} us, sparse product {t_sp:.1f} us, LUT + outliers {t_both:.1f} us, fp16 F.linear {t_fp:.1f} us", flush=True)
+    print(f"M={M}: LUT {t_plain:.1f} us, sparse product {t_sp:.1f} us, LUT + outliers {t_both:.1f} us (one call: {t_one:.1f} us), fp16 F.linear {t_fp:.1f} us", flush=True)
