@@ -206,6 +206,69 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
         const int bG = nb - 1 - s;  // panel whose residual is produced in this step (none at s = nb)
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         f32x4v bpre[4];  // (G) packed L block (source panel bG+1, this wave's tile): the B operands of part 2
+        // shared by both roles (the P waves run a chain too when they assist, see below)
+        const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);
+        // zero records: every load through it is out of range and returns 0
+        const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0, 0x00020000);
+        const int voff = lane * 16;  // this lane's 16 bytes inside each quarter of a packed block
+        // One chain segment: source panels phi, phi-1, .., plo (descending), A from LDS (panels >= pbase) or from
+        // the global scratch.  One batch = one source panel = 16 MFMAs; operands are loaded two batches ahead into
+        // three rotating register sets; every load is unconditional and the loop runs whole rounds of three
+        // (batches past the end read B through rsrcZ: zeros leave the accumulator as it is), so that the waits
+        // in the steady state count exactly the loads still allowed in flight.
+        auto chain = [&](auto a_in_lds, int phi, int plo, const int ct) {
+            constexpr bool ALDS = decltype(a_in_lds)::value;
+            const int nbat = phi - plo + 1;
+            if (nbat <= 0) return;
+            auto ld = [&](int bi, f32x4v (&aa)[4], f32x4v (&bb)[4]) {
+                const bool real = bi < nbat;
+                const int ps = phi - min(bi, nbat - 1);  // source panel of the batch
+                const uint32_t sB = (uint32_t)(ps * NT + ct) * 4096u;
+                const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
+                const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * 1024 + lane * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bb[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * j, (int)sB, 0));
+                    if constexpr (ALDS) aa[j] = Al[j * 64];
+                    else aa[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * j, ps * 4096, 0));
+                }
+            };
+            auto mm = [&](const f32x4v (&aa)[4], const f32x4v (&bb)[4]) {
+#pragma unroll
+                for (int g = 15; g >= 0; --g)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g >> 2][g & 3], bb[g >> 2][g & 3], acc, 0, 0, 0);
+            };
+            f32x4v a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
+            ld(0, a0, b0);
+            ld(1, a1, b1);
+            GANQ_PIN();
+            // one stage = the loads of batch k+2 spread between the 16 MFMAs of batch k
+            auto stage_sched = [&]() {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (B)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (ALDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (A)
+                    else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (A)
+                }
+            };
+            for (int bi = 0; bi < nbat; bi += 3) {  // whole rounds, no exits inside: a plain counted loop
+                ld(bi + 2, a2, b2);
+                mm(a0, b0);
+                stage_sched();
+                GANQ_PIN();
+                ld(bi + 3, a0, b0);
+                mm(a1, b1);
+                stage_sched();
+                GANQ_PIN();
+                ld(bi + 4, a1, b1);
+                mm(a2, b2);
+                stage_sched();
+                GANQ_PIN();
+            }
+        };
         if (!roleG) {
             // ---- (P) ---------------------------------------------------------------------------------------
             if (bP <= nb - 1) {
@@ -249,6 +312,14 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                     wnext[k] = (j0 + col < n) ? W[(int64_t)prow * n + j0 + col] : 0.0f;
                 }
             }
+#ifdef GANQ_SOLVE_DUP_G  // timing experiment: the P waves run a copy of the G chain (a second MFMA chain per SIMD)
+            if (bG >= 0) {
+                const int ctx = 4 * bG + gw, pl = max(bG + 2, pbase);
+                chain(std::true_type{}, nb - 1, pl, ctx);
+                chain(std::false_type{}, min(nb - 1, pl - 1), bG + 2, ctx);
+                if (acc[0] == 1.2345e33f) ErrPk[lane] = acc[1];
+            }
+#endif
         } else if (bG >= 0) {
             // ---- (G) part 1: the panels right of panel bG+1, descending --------------------------------------
             const int j0 = bG * SB;
@@ -264,78 +335,16 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
             }
             float dpre = 1.0f;
             if (gtid < SB && gtid < wd) dpre = L[(int64_t)(j0 + gtid) * ldl + j0 + gtid];
-            const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0xffffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);
-            // zero records: every load through it is out of range and returns 0
-            const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0, 0x00020000);
-            const int voff = lane * 16;  // this lane's 16 bytes inside each quarter of a packed block
             if (bG + 1 <= nb - 1) {
                 const uint32_t sb = (uint32_t)((bG + 1) * NT + ct) * 4096u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     bpre[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcL, voff + 1024 * j, (int)sb, 0));
             }
-            // One chain segment: source panels phi, phi-1, .., plo (descending), A from LDS (panels >= pbase) or from
-            // the global scratch.  One batch = one source panel = 16 MFMAs; operands are loaded two batches ahead into
-            // three rotating register sets; every load is unconditional and the loop runs whole rounds of three
-            // (batches past the end read B through rsrcZ: zeros leave the accumulator as it is), so that the waits
-            // in the steady state count exactly the loads still allowed in flight.
-            auto chain = [&](auto a_in_lds, int phi, int plo) {
-                constexpr bool ALDS = decltype(a_in_lds)::value;
-                const int nbat = phi - plo + 1;
-                if (nbat <= 0) return;
-                auto ld = [&](int bi, f32x4v (&aa)[4], f32x4v (&bb)[4]) {
-                    const bool real = bi < nbat;
-                    const int ps = phi - min(bi, nbat - 1);  // source panel of the batch
-                    const uint32_t sB = (uint32_t)(ps * NT + ct) * 4096u;
-                    const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
-                    const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * 1024 + lane * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bb[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * j, (int)sB, 0));
-                        if constexpr (ALDS) aa[j] = Al[j * 64];
-                        else aa[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * j, ps * 4096, 0));
-                    }
-                };
-                auto mm = [&](const f32x4v (&aa)[4], const f32x4v (&bb)[4]) {
-#pragma unroll
-                    for (int g = 15; g >= 0; --g)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g >> 2][g & 3], bb[g >> 2][g & 3], acc, 0, 0, 0);
-                };
-                f32x4v a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
-                ld(0, a0, b0);
-                ld(1, a1, b1);
-                GANQ_PIN();
-                // one stage = the loads of batch k+2 spread between the 16 MFMAs of batch k
-                auto stage_sched = [&]() {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (B)
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                        if (ALDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (A)
-                        else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (A)
-                    }
-                };
-                for (int bi = 0; bi < nbat; bi += 3) {  // whole rounds, no exits inside: a plain counted loop
-                    ld(bi + 2, a2, b2);
-                    mm(a0, b0);
-                    stage_sched();
-                    GANQ_PIN();
-                    ld(bi + 3, a0, b0);
-                    mm(a1, b1);
-                    stage_sched();
-                    GANQ_PIN();
-                    ld(bi + 4, a1, b1);
-                    mm(a2, b2);
-                    stage_sched();
-                    GANQ_PIN();
-                }
-            };
             const int plds = max(bG + 2, pbase);  // lowest source panel of this chain whose Err block lives in LDS
 #ifndef GANQ_SOLVE_NO_G  // timing experiment: results are meaningless without the residual chain
-            chain(std::true_type{}, nb - 1, plds);
-            chain(std::false_type{}, min(nb - 1, plds - 1), bG + 2);
+            chain(std::true_type{}, nb - 1, plds, ct);
+            chain(std::false_type{}, min(nb - 1, plds - 1), bG + 2, ct);
 #endif
 #pragma unroll
             for (int e = 0; e < (SB * SB) / 256; ++e) {
