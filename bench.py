@@ -98,12 +98,22 @@ def build_workload(args, dist, dev):
             torch.cuda.synchronize()
         t_hess += time.perf_counter() - t0
     torch.cuda.synchronize()
+    H_copy, n_copy = q.H.clone(), q.nsamples
     t0 = time.perf_counter()
     wq, _, _, _, _, avg_loss, damp = q.quantize()  # full quantize(): prologue + k-means + loop + epilogue
     torch.cuda.synchronize()
     t_full = time.perf_counter() - t0
+    # the same call again on the same statistics: the first one pays one-time costs (workspaces, library handles)
+    q2 = GANQ(NamedModule(lin, "proj", f"model.layers.0.proj{dist.rank}", 0), qcfg)
+    q2.quantizer.configure(perchannel=True)
+    q2.H, q2.nsamples = H_copy, n_copy
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    q2.quantize()
+    torch.cuda.synchronize()
+    t_full_warm = time.perf_counter() - t0
     setup = {"hessian_s": round(t_hess, 4), "xgmi_broadcast_s": round(t_bcast, 4), "kmeans_s": round(captured["kmeans_s"], 4),
-             "full_quantize_s": round(t_full, 4), "avg_loss": avg_loss, "damp_percent": damp,
+             "full_quantize_s": round(t_full, 4), "full_quantize_warm_s": round(t_full_warm, 4), "avg_loss": avg_loss, "damp_percent": damp,
              "calib_bytes": args.nseq * args.seqlen * n * 2}
     return captured, setup
 
