@@ -73,6 +73,33 @@ def test_prologue_hip_matches_reference_op_sequence():
     assert float(((mine.double() - exact).abs() / exact).max()) <= 2 * float(((ref.double() - exact).abs() / exact).max()) + 1e-6
 
 
+@pytest.mark.parametrize("prologue", ["hip", "torch"])
+def test_damp_retry_on_indefinite_hessian(prologue):
+    """gptq.py:296-319: a Hessian that is not positive definite after damping raises LinAlgError inside the prologue;
+    with damp_auto_increment the damping grows until the factorisation succeeds, without it the error propagates"""
+    from ganq_amd.looper.named_module import NamedModule
+    from ganq_amd.quantization import GANQ, QuantizeConfig
+
+    torch.manual_seed(0)
+    n, m = 256, 64
+    lin = nn.Linear(n, m, bias=False).half().cuda()
+    X = torch.randn(1, 32, n, device="cuda").half()  # 32 tokens for 256 features: rank-deficient H
+
+    def run(**kw):
+        qcfg = QuantizeConfig(bits=4, act_sort="none", desc_act=False, l_damp_style="ganq", dead="zero", ganq_iterations=1,
+                              ganq_prologue=prologue, **kw)
+        q = GANQ(NamedModule(lin, "fc", "layers.0.fc", 0), qcfg)
+        q.quantizer.configure(perchannel=True)
+        q.add_batch(X, None)
+        q.H -= 0.05 * torch.diag(q.H).mean() * torch.eye(n, device="cuda")  # push the null space below zero
+        return q.quantize()
+
+    with pytest.raises(torch.linalg.LinAlgError):
+        run(damp_percent=0.01, damp_auto_increment=0.0)
+    out = run(damp_percent=0.01, damp_auto_increment=0.02)
+    assert out[6] > 0.01 and np.isfinite(out[5])  # the damping that finally worked is reported (7-tuple, gptq.py:375)
+
+
 def test_quantizer_rejects_cpu_module_and_bits8():
     from ganq_amd import _lib
     from ganq_amd.quantization import GANQ, QuantizeConfig
