@@ -52,6 +52,7 @@ def init_from_env(backend: Optional[str] = None) -> Dist:
     share = os.environ.get("GANQ_DIST_SHARE_DEVICE", "") == "1"
     if use_cuda:
         torch.cuda.set_device(0 if share else local)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if not td.is_initialized():
