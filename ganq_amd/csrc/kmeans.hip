@@ -52,6 +52,12 @@ __device__ unsigned long long km_dbg[32];
 #define KM_STAMP(slot) do {} while (0)
 #endif
 
+// Barrier for data exchanged through LDS only.  __syncthreads() also waits for this wave's outstanding GLOBAL stores
+// (s_waitcnt vmcnt(0)); the levels of a DP layer hand each other nothing but the argmins in LDS, while every node also
+// stores D[k][i] and its argmin to global memory (read again at the next layer / the backtrack, behind a full
+// barrier) -- waiting for those stores at each of the ~170 level barriers per row exposed a store round trip each time.
+__device__ __forceinline__ void km_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double km_cost4(double cwj, double cwxj, double cwxxj, double cw_i1, double cwx_i1, double cwxx_i1) {
     const double w = cw_i1 - cwj;
     const double wx = cwx_i1 - cwxj;
@@ -137,23 +143,28 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
 // spread evenly over all 1024 threads.  The per-node minimum over the spread items is an LDS atomic min on the cost
 // bits (non-negative doubles order like their bit patterns), the leftmost-argmin tie-break a second atomic min on j
 // among the items that reached that cost -- the same (cost, j) order as a sequential scan.
-constexpr int KB_CAP = 8;      // candidates a node evaluates itself (4096x4096, V=16: 1 -> 27.4, 2 -> 18.3, 4 -> 17.5, 8 -> 17.2 ms)
-constexpr int KB_QMAX = 512;   // queued ranges per level (more: finished in place)
-constexpr int KB_SLOTS = 8;    // spread items per thread (covers n + nodes <= 8192 items)
+#ifndef KB_CAP
+#define KB_CAP 12              // candidates every node evaluates itself, unrolled (4096x4096, V = 16 on MI355X: 2 -> 23.0 ms,
+                               // 3 -> 20.6, 4 -> 19.4, 6 -> 17.7, 8 -> 17.1, 12 -> 16.9, 16 -> 17.3: the independent cost
+                               // evaluations of one node overlap, a queued range costs a pass over the queue)
+#endif
+constexpr int KB_QMAX = 1024;  // queued ranges per level (more: finished in place)
 struct KmQueue {               // LDS scratch of the balanced levels
-    unsigned long long ctr;                 // (entries << 32) | items
-    unsigned long long cost[KB_QMAX];       // min cost bits over the spread items
+    unsigned int count;
+    unsigned int pad;
     unsigned long long seedc[KB_QMAX];      // best of the node's own first KB_CAP candidates
-    unsigned int off[KB_QMAX];              // first flat item of the range
-    unsigned int j[KB_QMAX];                // leftmost argmin among the spread items
     unsigned int seedj[KB_QMAX];
     unsigned short t[KB_QMAX], jstart[KB_QMAX], cnt[KB_QMAX];
 };
 
+// One level with many nodes.  Most nodes have two or three candidates, a few (where the argmin jumps at a cluster
+// boundary) have hundreds.  Pass A: every node evaluates its first KB_CAP candidates, unrolled -- no lane waits for a
+// neighbour's longer loop; what is left of a range is queued.  Pass B: the queued ranges are dealt to 32 groups of 32
+// lanes, 32 candidates per step, (cost, leftmost j) reduced inside the group.  The minimum with its tie-break is
+// order-independent, so who scans what does not change the result.
 __device__ __forceinline__ void km_level_balanced(const double* cw, const double* cwx, const double* cwxx, const double* dprev,
                                                   uint16_t* acur, double* dcur, int* ag, int cnt, int hs, int n, KmQueue* q) {
     const int tid = threadIdx.x;
-    // ---- A: own candidates, queue the rest ----
     for (int t = tid; t < cnt; t += KL_THREADS) {
         const int i = hs - 1 + t * 2 * hs;
         const int lo = (i - hs >= 0) ? (int)acur[i - hs] : 0;
@@ -162,25 +173,24 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
         const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
         double bc = INFINITY;
         int bj = 0x7fffffff;
-        const int own_hi = min(hi, lo + KB_CAP - 1);
-        for (int j = lo; j <= own_hi; ++j) km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
-        const int rest = hi - own_hi;
+#pragma unroll
+        for (int c = 0; c < KB_CAP; ++c) {
+            const int j = min(lo + c, hi);  // past the range: the last candidate again (same cost, same j: no effect)
+            km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+        }
+        const int rest = hi - (lo + KB_CAP - 1);
         bool queued = false;
         if (rest > 0) {
-            const unsigned long long e = atomicAdd(&q->ctr, (1ull << 32) | (unsigned long long)rest);
-            const unsigned int idx = (unsigned int)(e >> 32);
+            const unsigned int idx = atomicAdd(&q->count, 1u);
             if (idx < (unsigned int)KB_QMAX) {
                 q->t[idx] = (unsigned short)t;
-                q->jstart[idx] = (unsigned short)(own_hi + 1);
+                q->jstart[idx] = (unsigned short)(lo + KB_CAP);
                 q->cnt[idx] = (unsigned short)min(rest, 65535);
-                q->off[idx] = (unsigned int)e;
-                q->cost[idx] = 0x7ff0000000000000ull;  // +inf
-                q->j[idx] = 0xffffffffu;
                 q->seedc[idx] = (unsigned long long)__double_as_longlong(bc);
                 q->seedj[idx] = (unsigned int)bj;
                 queued = true;
             } else {
-                for (int j = own_hi + 1; j <= hi; ++j)
+                for (int j = lo + KB_CAP; j <= hi; ++j)
                     km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
             }
         }
@@ -190,58 +200,35 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
             acur[i] = (uint16_t)bj;
         }
     }
-    __syncthreads();
-    // ---- B: the queued candidates as one flat item space, KL_THREADS items at a time ----
-    const unsigned long long ctr = q->ctr;
-    const int nq = min((int)(ctr >> 32), KB_QMAX);
-    const unsigned int total = (unsigned int)ctr;
-    unsigned long long sc[KB_SLOTS];
-    int se[KB_SLOTS], sj[KB_SLOTS];
-#pragma unroll
-    for (int r = 0; r < KB_SLOTS; ++r) {
-        se[r] = -1;
-        const unsigned int w = (unsigned int)tid + (unsigned int)r * KL_THREADS;
-        if (w < total && nq > 0) {
-            int lo_e = 0, hi_e = nq - 1;  // largest entry with off <= w (offsets ascend with the entry index)
-            while (lo_e < hi_e) {
-                const int mid = (lo_e + hi_e + 1) >> 1;
-                if (q->off[mid] <= w) lo_e = mid; else hi_e = mid - 1;
-            }
-            const unsigned int d = w - q->off[lo_e];
-            if (q->off[lo_e] <= w && d < (unsigned int)q->cnt[lo_e]) {
-                const int t = q->t[lo_e];
-                const int i = hs - 1 + t * 2 * hs;
-                const int j = (int)q->jstart[lo_e] + (int)d;
-                const double c = dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], cw[i + 1], cwx[i + 1], cwxx[i + 1]);
-                const unsigned long long cb = (unsigned long long)__double_as_longlong(c);
-                atomicMin(&q->cost[lo_e], cb);
-                sc[r] = cb;
-                se[r] = lo_e;
-                sj[r] = j;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- C: leftmost item among those that reached the minimum ----
-#pragma unroll
-    for (int r = 0; r < KB_SLOTS; ++r)
-        if (se[r] >= 0 && sc[r] == q->cost[se[r]]) atomicMin(&q->j[se[r]], (unsigned int)sj[r]);
-    __syncthreads();
-    // ---- D: a node's own candidates lie left of its queued ones: they win ties ----
-    for (int e = tid; e < nq; e += KL_THREADS) {
+    km_lds_barrier();
+    const int nq = min((int)q->count, KB_QMAX);
+    const int grp = tid >> 5, l32 = tid & 31;
+    for (int e = grp; e < nq; e += KL_THREADS / 32) {
         const int i = hs - 1 + (int)q->t[e] * 2 * hs;
-        unsigned long long cb = q->seedc[e];
-        unsigned int bj = q->seedj[e];
-        if (q->cost[e] < cb) {
-            cb = q->cost[e];
-            bj = q->j[e];
+        const int j0 = (int)q->jstart[e], len = (int)q->cnt[e];
+        const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
+        double bc = INFINITY;
+        int bj = 0x7fffffff;
+        for (int d = l32; d < len; d += 32) {
+            const int j = j0 + d;
+            km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
         }
-        dcur[i] = __longlong_as_double((long long)cb);
-        ag[i] = (int)bj;
-        acur[i] = (uint16_t)bj;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            const double oc = __shfl_xor(bc, off);
+            const int oj = __shfl_xor(bj, off);
+            km_better(bc, bj, oc, oj);
+        }
+        if (l32 == 0) {
+            km_better(bc, bj, __longlong_as_double((long long)q->seedc[e]), (int)q->seedj[e]);  // own candidates lie left: they win ties
+            dcur[i] = bc;
+            ag[i] = bj;
+            acur[i] = (uint16_t)bj;
+        }
     }
-    if (tid == 0) q->ctr = 0;
-    __syncthreads();
+    km_lds_barrier();
+    if (tid == 0) q->count = 0;
+    km_lds_barrier();
 }
 
 __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __restrict__ W, const double* __restrict__ col_weight,
@@ -356,7 +343,7 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
         __syncthreads();
 
         KM_STAMP(1);
-        if (tid == 0) kq->ctr = 0;
+        if (tid == 0) kq->count = 0;
         // ---- 3. DP ----------------------------------------------------------------------------------------
         for (int i = tid; i < n; i += KL_THREADS) {
             dcur[i] = km_cost4(cw[0], cwx[0], cwxx[0], cw[i + 1], cwx[i + 1], cwxx[i + 1]);
@@ -364,8 +351,9 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
         }
         __syncthreads();
         for (int k = 1; k < V; ++k) {
+            __syncthreads();  // full barrier: D[k-1] (global) of every thread is complete
             for (int j = tid; j <= n; j += KL_THREADS) dprev[j] = (j == 0) ? 0.0 : dcur[j - 1];
-            __syncthreads();
+            km_lds_barrier();
             KM_STAMP(2);
             int* ag = arg + (size_t)k * n;
             {   // position n-1: full scan by the whole workgroup
@@ -384,14 +372,14 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
                     red_c[tid >> 6] = bc;
                     red_j[tid >> 6] = bj;
                 }
-                __syncthreads();
+                km_lds_barrier();
                 if (tid == 0) {
                     for (int w = 1; w < KL_THREADS / 64; ++w) km_better(bc, bj, red_c[w], red_j[w]);
                     dcur[i] = bc;
                     ag[i] = bj;
                     acur[i] = (uint16_t)bj;
                 }
-                __syncthreads();
+                km_lds_barrier();
             }
             KM_STAMP(3);
             if (k == V - 1) break;  // only D[V-1][n-1] is needed from the last layer
@@ -401,11 +389,11 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
                 int G = 1;
                 while (G < KL_THREADS && G * 2 * cnt <= KL_THREADS) G <<= 1;
                 const int lg = tid & (G - 1);
-                if (cnt >= 128 && cnt <= KB_SLOTS * KL_THREADS - n) {
+                if (cnt >= 128) {
                     km_level_balanced(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
                 } else if (G <= 64) {
                     km_level_nodes(cw, cwx, cwxx, dprev, 0, cw, cwx, cwxx, acur, dcur, ag, 0, cnt - 1, hs, n, G);
-                    __syncthreads();
+                    km_lds_barrier();
                 } else {
                     // few nodes: several waves per node, partial minima through LDS
                     const int t = tid / G;
@@ -429,7 +417,7 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
                         red_c[tid >> 6] = bc;
                         red_j[tid >> 6] = bj;
                     }
-                    __syncthreads();
+                    km_lds_barrier();
                     if (lg == 0 && t < cnt) {
                         const int w0 = tid >> 6;
                         for (int w = 1; w < G / 64; ++w) km_better(bc, bj, red_c[w0 + w], red_j[w0 + w]);
@@ -437,12 +425,13 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
                         ag[i] = bj;
                         acur[i] = (uint16_t)bj;
                     }
-                    __syncthreads();
+                    km_lds_barrier();
                 }
                 KM_STAMP(4 + (31 - __builtin_clz(hs)));
             }
         }
 
+        __syncthreads();  // the argmins of every layer (global) are complete before the backtrack reads them
         // ---- 4. backtrack + centroids ------------------------------------------------------------------------
         if (tid == 0) {
             int end = n - 1;
