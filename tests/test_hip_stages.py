@@ -249,6 +249,30 @@ def test_run_layer_incremental_equals_full(hip, m, n, V, K, seed, monkeypatch):
             assert out[3] == ref[3]
 
 
+def test_run_layer_incremental_many_changes(hip, monkeypatch):
+    # a poor initial codebook makes a large share of the indices change in the first update: more than 32 per pass and
+    # more than the 512 per row the matrix-core kernel caches in LDS; never falling back must equal always re-accumulating
+    m, n, V, K = 24, 2048, 16, 3
+    W, H, L, T0 = synth(m, n, V, 77, corr=0.1)
+    rng = np.random.default_rng(5)
+    T0 = np.sort(rng.uniform(-0.1, 0.1, size=T0.shape).astype(np.float32), axis=1)  # unrelated to the weights
+    args = (dev(W), dev(H), dev(L), dev(T0), K)
+    q_first = hip.run_layer(*args[:4], 1, alias_q=True)[1]   # with the aliasing: the indices of the last iteration
+    q_second = hip.run_layer(*args[:4], 2, alias_q=True)[1]
+    per_row = (q_first != q_second).sum(dim=1)
+    assert int(per_row.max()) > 512 and int(per_row.min()) > 32, per_row
+    outs = []
+    for env in ({"GANQ_T_FULL": "1"}, {"GANQ_T_INCR_THR": str(m * n)}, {"GANQ_T_INCR_THR": str(m * n), "GANQ_MUPDATE_LDS": "1"}):
+        for k in ("GANQ_T_FULL", "GANQ_T_INCR_THR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        T, Q, d, bk = hip.run_layer(*args, alias_q=False)
+        outs.append((T.clone(), Q.clone(), d.clone(), int(bk)))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+
+
 def test_reciprocal_quotient_equals_ieee_division(hip):
     # the S-solve replaces r / L[j][j] by a reciprocal-based sequence that must round like the division
     bad, first = hip.debug_div_check(1 << 30, seed=7)
