@@ -196,6 +196,35 @@ def test_looper_shared_group_hessian_is_identical():
 
 
 @torch.no_grad()
+def test_looper_early_exit_is_identical():
+    # stopping a group's calibration forward once its modules have seen the batch must not change any statistic
+    from ganq_amd.looper.gptq_processor import GPTQProcessor
+    from ganq_amd.looper.module_looper import ModuleLooper
+    from ganq_amd.quantization import QuantizeConfig
+
+    res, outs, calls = [], [], []
+    for early in (False, True):
+        torch.manual_seed(0)
+        model = nn.Module()
+        model.layers = nn.ModuleList([ToyLayer(64, 128), ToyLayer(64, 128)])
+        model = model.half().cuda()
+        count = [0]
+        model.layers[0].fc2.register_forward_hook(lambda *_: count.__setitem__(0, count[0] + 1))
+        xs = [torch.randn(2, 48, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9 + i)).half()
+              for i in range(3)]
+        proc = GPTQProcessor(QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2))
+        out = ModuleLooper(proc, model.layers, [["q_proj", "k_proj", "v_proj"], ["out_proj"], ["fc1"], ["fc2"]],
+                           layers_prefix="layers", share_group_hessian=True, early_exit=early).loop(xs)
+        res.append({k: (v["ganq_q"].clone(), v["ganq_lut"].clone()) for k, v in proc.results().items()})
+        outs.append([o.clone() for o in out])
+        calls.append(count[0])
+    assert len(res[0]) == 12 and calls[0] == 5 * 3 and calls[1] == 2 * 3  # fc2 of layer 0: 5 passes x 3 batches vs 2 x 3
+    for k in res[0]:
+        assert torch.equal(res[0][k][0], res[1][k][0]) and torch.equal(res[0][k][1], res[1][k][1]), k
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+@torch.no_grad()
 def test_looper_reports_modules_without_calibration_data():
     # a module of a group that is never invoked (MoE expert without routed tokens) is reported and left as it is
     from ganq_amd.looper.gptq_processor import GPTQProcessor
