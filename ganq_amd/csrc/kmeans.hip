@@ -148,14 +148,26 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
                                // 3 -> 20.6, 4 -> 19.4, 6 -> 17.7, 8 -> 17.1, 12 -> 16.9, 16 -> 17.3: the independent cost
                                // evaluations of one node overlap, a queued range costs a pass over the queue)
 #endif
-constexpr int KB_QMAX = 1024;  // queued ranges per level (more: finished in place)
-struct KmQueue {               // LDS scratch of the balanced levels
-    unsigned int count;
-    unsigned int pad;
-    unsigned long long seedc[KB_QMAX];      // best of the node's own first KB_CAP candidates
-    unsigned int seedj[KB_QMAX];
-    unsigned short t[KB_QMAX], jstart[KB_QMAX], cnt[KB_QMAX];
+struct KmQueue {               // LDS scratch of the balanced levels: `cap` queued ranges per level (more: finished in place)
+    unsigned int* count;
+    unsigned long long* seedc;              // best of the node's own first KB_CAP candidates
+    unsigned int* seedj;
+    unsigned short *t, *jstart, *cnt;
+    int cap;
 };
+__host__ __device__ inline size_t km_queue_bytes(int cap) { return 16 + (size_t)cap * (8 + 4 + 2 + 2 + 2); }
+__host__ inline int km_queue_cap(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(128, (n / 4 + 63) / 64 * 64)); }
+__device__ __forceinline__ KmQueue km_queue_at(char* base, int cap) {
+    KmQueue q;
+    q.count = reinterpret_cast<unsigned int*>(base);
+    q.seedc = reinterpret_cast<unsigned long long*>(base + 16);
+    q.seedj = reinterpret_cast<unsigned int*>(base + 16 + (size_t)cap * 8);
+    q.t = reinterpret_cast<unsigned short*>(base + 16 + (size_t)cap * 12);
+    q.jstart = q.t + cap;
+    q.cnt = q.jstart + cap;
+    q.cap = cap;
+    return q;
+}
 
 // One level with many nodes.  Most nodes have two or three candidates, a few (where the argmin jumps at a cluster
 // boundary) have hundreds.  Pass A: every node evaluates its first KB_CAP candidates, unrolled -- no lane waits for a
@@ -163,7 +175,7 @@ struct KmQueue {               // LDS scratch of the balanced levels
 // lanes, 32 candidates per step, (cost, leftmost j) reduced inside the group.  The minimum with its tie-break is
 // order-independent, so who scans what does not change the result.
 __device__ __forceinline__ void km_level_balanced(const double* cw, const double* cwx, const double* cwxx, const double* dprev,
-                                                  uint16_t* acur, double* dcur, int* ag, int cnt, int hs, int n, KmQueue* q) {
+                                                  uint16_t* acur, double* dcur, int* ag, int cnt, int hs, int n, const KmQueue& q) {
     const int tid = threadIdx.x;
     for (int t = tid; t < cnt; t += KL_THREADS) {
         const int i = hs - 1 + t * 2 * hs;
@@ -181,13 +193,13 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
         const int rest = hi - (lo + KB_CAP - 1);
         bool queued = false;
         if (rest > 0) {
-            const unsigned int idx = atomicAdd(&q->count, 1u);
-            if (idx < (unsigned int)KB_QMAX) {
-                q->t[idx] = (unsigned short)t;
-                q->jstart[idx] = (unsigned short)(lo + KB_CAP);
-                q->cnt[idx] = (unsigned short)min(rest, 65535);
-                q->seedc[idx] = (unsigned long long)__double_as_longlong(bc);
-                q->seedj[idx] = (unsigned int)bj;
+            const unsigned int idx = atomicAdd(q.count, 1u);
+            if (idx < (unsigned int)q.cap) {
+                q.t[idx] = (unsigned short)t;
+                q.jstart[idx] = (unsigned short)(lo + KB_CAP);
+                q.cnt[idx] = (unsigned short)min(rest, 65535);
+                q.seedc[idx] = (unsigned long long)__double_as_longlong(bc);
+                q.seedj[idx] = (unsigned int)bj;
                 queued = true;
             } else {
                 for (int j = lo + KB_CAP; j <= hi; ++j)
@@ -201,11 +213,11 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
         }
     }
     km_lds_barrier();
-    const int nq = min((int)q->count, KB_QMAX);
+    const int nq = min((int)*q.count, q.cap);
     const int grp = tid >> 5, l32 = tid & 31;
     for (int e = grp; e < nq; e += KL_THREADS / 32) {
-        const int i = hs - 1 + (int)q->t[e] * 2 * hs;
-        const int j0 = (int)q->jstart[e], len = (int)q->cnt[e];
+        const int i = hs - 1 + (int)q.t[e] * 2 * hs;
+        const int j0 = (int)q.jstart[e], len = (int)q.cnt[e];
         const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
         double bc = INFINITY;
         int bj = 0x7fffffff;
@@ -220,20 +232,23 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
             km_better(bc, bj, oc, oj);
         }
         if (l32 == 0) {
-            km_better(bc, bj, __longlong_as_double((long long)q->seedc[e]), (int)q->seedj[e]);  // own candidates lie left: they win ties
+            km_better(bc, bj, __longlong_as_double((long long)q.seedc[e]), (int)q.seedj[e]);  // own candidates lie left: they win ties
             dcur[i] = bc;
             ag[i] = bj;
             acur[i] = (uint16_t)bj;
         }
     }
     km_lds_barrier();
-    if (tid == 0) q->count = 0;
+    if (tid == 0) *q.count = 0;
     km_lds_barrier();
 }
 
-__global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __restrict__ W, const double* __restrict__ col_weight,
-                                                                int m, int n, int V, int P, float* __restrict__ T0,
-                                                                char* __restrict__ ws, size_t ws_stride) {
+// MINW = waves per SIMD the register allocation must allow: 4 (one workgroup per CU) or 8 (two, when two rows' arrays
+// fit the LDS together: n <= 2.3 k)
+template <int MINW>
+__global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const float* __restrict__ W, const double* __restrict__ col_weight,
+                                                                      int m, int n, int V, int P, int qcap, float* __restrict__ T0,
+                                                                      char* __restrict__ ws, size_t ws_stride) {
     extern __shared__ __align__(16) char km_smem[];
     const int n1 = n + 1;
     double* cw = reinterpret_cast<double*>(km_smem);
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
     double* cwxx = cwx + n1;
     double* dprev = cwxx + n1;
     uint16_t* acur = reinterpret_cast<uint16_t*>(dprev + n1);  // [n] argmins of the layer being solved
-    KmQueue* kq = reinterpret_cast<KmQueue*>(km_smem + align_up(4 * (size_t)n1 * sizeof(double) + (size_t)n * sizeof(uint16_t), 16));
+    const KmQueue kq = km_queue_at(km_smem + align_up(4 * (size_t)n1 * sizeof(double) + (size_t)n * sizeof(uint16_t), 16), qcap);
     uint64_t* keys = reinterpret_cast<uint64_t*>(km_smem);     // [P] during the sort only (8P <= 16(n+1): over cw, cwx)
     double* ctot = dprev;                                       // [3][nchunk] during the prefix sums only
     __shared__ double red_c[KL_THREADS / 64];
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_lds_kernel(const float* __r
         __syncthreads();
 
         KM_STAMP(1);
-        if (tid == 0) kq->count = 0;
+        if (tid == 0) *kq.count = 0;
         // ---- 3. DP ----------------------------------------------------------------------------------------
         for (int i = tid; i < n; i += KL_THREADS) {
             dcur[i] = km_cost4(cw[0], cwx[0], cwxx[0], cw[i + 1], cwx[i + 1], cwxx[i + 1]);
@@ -721,7 +736,7 @@ __global__ __launch_bounds__(KL_THREADS) void kmeans_win_kernel(const float* __r
 
 struct KmPlan {
     bool lds;
-    int grid, P, Wcap;
+    int grid, P, Wcap, qcap = 0, per_cu = 1;
     size_t smem, stride;
 };
 constexpr size_t KM_LDS_BUDGET = 160 * 1024 - 1024;  // dynamic part; the rest covers the static reduction slots
@@ -731,7 +746,8 @@ static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
     while (p.P < n) p.P <<= 1;
     p.Wcap = 0;
     const size_t acur_bytes = align_up((size_t)n * sizeof(uint16_t), 16);
-    const size_t lds_bytes = align_up(4 * (size_t)(n + 1) * sizeof(double) + (size_t)n * sizeof(uint16_t), 16) + sizeof(KmQueue);
+    p.qcap = km_queue_cap(n);
+    const size_t lds_bytes = align_up(4 * (size_t)(n + 1) * sizeof(double) + (size_t)n * sizeof(uint16_t), 16) + km_queue_bytes(p.qcap);
     p.lds = lds_bytes <= KM_LDS_BUDGET;
     const char* force = getenv("GANQ_KMEANS_WCAP");  // testing: force the windowed kernel with a small window
     const int forced = force ? atoi(force) : 0;
@@ -739,6 +755,7 @@ static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
     if (p.lds) {
         p.smem = lds_bytes;
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (KM_LDS_BUDGET + 1024) / (lds_bytes + 1024)));
+        p.per_cu = per_cu;
         p.grid = (int)std::min<int64_t>(m, 256 * per_cu);
         p.stride = align_up(3 * (size_t)n * sizeof(double) + (size_t)V * (size_t)n * sizeof(int), 256);
     } else {
@@ -775,14 +792,24 @@ extern "C" int ganq_kmeans_init(const float* W, const double* col_weight, int64_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static size_t attr_smem[2] = {0, 0};
     if (p.smem > attr_smem[p.lds]) {
-        const void* fn = p.lds ? reinterpret_cast<const void*>(kmeans_lds_kernel) : reinterpret_cast<const void*>(kmeans_win_kernel);
-        GANQ_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
+        if (p.lds) {
+            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_lds_kernel<4>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
+            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_lds_kernel<8>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
+        } else {
+            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_win_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
+        }
         attr_smem[p.lds] = p.smem;
     }
     ProfScope prof(KID_KMEANS, stream);
-    if (p.lds)
-        hipLaunchKernelGGL(kmeans_lds_kernel, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n, V, p.P,
-                           T0, static_cast<char*>(workspace), p.stride);
+    if (p.lds && p.per_cu >= 2)
+        hipLaunchKernelGGL(kmeans_lds_kernel<8>, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n, V,
+                           p.P, p.qcap, T0, static_cast<char*>(workspace), p.stride);
+    else if (p.lds)
+        hipLaunchKernelGGL(kmeans_lds_kernel<4>, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n, V,
+                           p.P, p.qcap, T0, static_cast<char*>(workspace), p.stride);
     else
         hipLaunchKernelGGL(kmeans_win_kernel, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n, V,
                            p.P, p.Wcap, T0, static_cast<char*>(workspace), p.stride);
