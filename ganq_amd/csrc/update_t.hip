@@ -281,7 +281,12 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 #ifndef GANQ_JACOBI_SWEEPS
 #define GANQ_JACOBI_SWEEPS 30
 #endif
-constexpr int JS = 17;  // padded leading dimension of the fp64 16x16 matrices in LDS
+constexpr int JS = 17;
+#ifdef GANQ_T_NO_FAST_SOLVE  // A/B switch: always the Jacobi eigen-solve
+constexpr bool kNoFastSolve = true;
+#else
+constexpr bool kNoFastSolve = false;
+#endif  // padded leading dimension of the fp64 16x16 matrices in LDS
 
 __device__ __forceinline__ double row16_sum(double x) {
     x += __shfl_xor(x, 1, 16);
@@ -762,96 +767,147 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     }
     wave_sync();
 
-    // ---- round-robin Jacobi: 15 rounds of 8 disjoint rotations per sweep ----
-    const int t = l >> 1;  // pair handled (redundantly) by lanes 2t, 2t+1
-    for (int sweep = 0; sweep < GANQ_JACOBI_SWEEPS; ++sweep) {
-        double off = 0.0, dg = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double x = A[l][j];
-            if (j == l) dg += x * x; else off += x * x;
-        }
-        off = row16_sum(off);
-        dg = row16_sum(dg);
-        // squared off-diagonal mass below 1e-22 of the diagonal's: the eigenvalues are then converged to ~1e-22 relative
-        // (second order), the eigenvectors to ~1e-11 -- six orders below what the fp32 codebook keeps
-        const bool done = (off <= 1e-22 * dg) || (off == 0.0);
-        if (__all(done)) break;
-        for (int r = 0; r < 15; ++r) {
-            int p, q;
-            if (t == 0) {
-                p = r;
-                q = 15;
-            } else {
-                const int x = (r + t) % 15, y = (r - t + 15) % 15;
-                p = min(x, y);
-                q = max(x, y);
-            }
-            const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
-            double cc = 1.0, ss = 0.0;
-            if (apq != 0.0 && !done) {
-                // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)) with theta = alpha / apq, written without forming theta:
-                // t = sgn(alpha) apq / (|alpha| + hypot(alpha, apq))  -- one division and one square root fewer
-                const double alpha = 0.5 * (aqq - app);
-                const double rr = sqrt(alpha * alpha + apq * apq);
-                const double tt = (alpha >= 0.0 ? apq : -apq) / (fabs(alpha) + rr);
-                cc = 1.0 / sqrt(tt * tt + 1.0);
-                ss = tt * cc;
-            }
-            if ((l & 1) == 0) {
-                CS[rs][t][0] = cc;
-                CS[rs][t][1] = ss;
-            }
-            wave_sync();
-            // column phase: lane l rotates row l's entries (p_i, q_i) for all 8 pairs
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int pi, qi;
-                if (i == 0) { pi = r; qi = 15; } else {
-                    const int x = (r + i) % 15, y = (r - i + 15) % 15;
-                    pi = min(x, y); qi = max(x, y);
-                }
-                const double ci = CS[rs][i][0], si = CS[rs][i][1];
-                const double akp = A[l][pi], akq = A[l][qi];
-                A[l][pi] = ci * akp - si * akq;
-                A[l][qi] = si * akp + ci * akq;
-                const double ekp = E[l][pi], ekq = E[l][qi];
-                E[l][pi] = ci * ekp - si * ekq;
-                E[l][qi] = si * ekp + ci * ekq;
-            }
-            wave_sync();
-            // row phase: lane l rotates column l's entries of rows (p_i, q_i)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int pi, qi;
-                if (i == 0) { pi = r; qi = 15; } else {
-                    const int x = (r + i) % 15, y = (r - i + 15) % 15;
-                    pi = min(x, y); qi = max(x, y);
-                }
-                const double ci = CS[rs][i][0], si = CS[rs][i][1];
-                const double apk = A[pi][l], aqk = A[qi][l];
-                A[pi][l] = ci * apk - si * aqk;
-                A[qi][l] = si * apk + ci * aqk;
-            }
-            wave_sync();
-        }
-    }
-
-    // ---- minimum-norm solution: x = sum_k [|lam_k| > rcond * lam_max] (e_k . b / lam_k) e_k ----
-    const double lam = A[l][l];
-    const double lmax = row16_max(fabs(lam));
-    Coef[rs][l] = bl;
-    wave_sync();
-    double proj = 0.0;
-#pragma unroll
-    for (int a = 0; a < 16; ++a) proj += E[a][l] * Coef[rs][a];
-    wave_sync();
-    const bool keep = fabs(lam) > rcond * lmax;
-    Coef[rs][l] = keep ? proj / lam : 0.0;
-    wave_sync();
+    // ---- fast path.  gelsd keeps every singular value larger than rcond * sigma_max; when the row's A is positive
+    //      definite with  sigma_min >= 1 / ||L^-1||_F^2  >  4 rcond trace(A) >= 4 rcond sigma_max  (a guaranteed bound
+    //      from its Cholesky factor), nothing is cut off and the minimum-norm solution is simply A^-1 b.  Then
+    //      t = L^-T (L^-1 b) needs 16 pivots instead of ~60 Jacobi rounds.  All in registers: lane l owns row l of L and
+    //      column l of L^-1, values travel by 16-lane shuffles.  Rows with an unused code (a zero pivot), a tiny
+    //      pivot or a large inverse take the Jacobi path below, and so does the whole wave then.
     double x = 0.0;
+    bool fast = false;
+    if (!kNoFastSolve) {
+        double r[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x += E[l][k] * Coef[rs][k];
+        for (int a = 0; a < 16; ++a) r[a] = (l < V && a < V) ? colA[a] : ((a == l) ? 1.0 : 0.0);  // A[l][a] (symmetric)
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const double dk = __shfl(r[k], k, 16);
+            ok = ok && (dk > 0.0);
+            const double sk = sqrt(dk);
+            const double lk = (l == k) ? sk : r[k] / sk;  // L[l][k] for l >= k
+            r[k] = lk;
+#pragma unroll
+            for (int j = k + 1; j < 16; ++j) r[j] -= lk * __shfl(lk, j, 16);  // A[l][j] -= L[l][k] L[j][k]
+        }
+        double xc[16], yv[16];  // column l of L^-1; y = L^-1 b (every lane holds all of it)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sx = (i == l) ? 1.0 : 0.0;
+            double sy = __shfl(bl, i, 16);
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                const double lij = __shfl(r[j], i, 16);
+                sx -= lij * xc[j];
+                sy -= lij * yv[j];
+            }
+            const double lii = __shfl(r[i], i, 16);
+            xc[i] = sx / lii;
+            yv[i] = sy / lii;
+        }
+        double n2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            n2 += xc[i] * xc[i];
+            x += xc[i] * yv[i];  // t_l = (L^-T y)_l = sum_i L^-1[i][l] y_i
+        }
+        const double inv_norm2 = row16_sum(l < V ? n2 : 0.0);     // ||L^-1||_F^2 >= 1 / sigma_min(A)
+        const double tr = row16_sum(l < V ? colA[l] : 0.0);       // trace(A) >= sigma_max(A)
+        const bool row_ok = ok && (4.0 * rcond * tr * inv_norm2 < 1.0);  // false for NaN
+        fast = __all(row_ok);
+    }
+    if (!fast) {
+        // ---- round-robin Jacobi: 15 rounds of 8 disjoint rotations per sweep ----
+        const int t = l >> 1;  // pair handled (redundantly) by lanes 2t, 2t+1
+        for (int sweep = 0; sweep < GANQ_JACOBI_SWEEPS; ++sweep) {
+            double off = 0.0, dg = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double x = A[l][j];
+                if (j == l) dg += x * x; else off += x * x;
+            }
+            off = row16_sum(off);
+            dg = row16_sum(dg);
+            // squared off-diagonal mass below 1e-22 of the diagonal's: the eigenvalues are then converged to ~1e-22 relative
+            // (second order), the eigenvectors to ~1e-11 -- six orders below what the fp32 codebook keeps
+            const bool done = (off <= 1e-22 * dg) || (off == 0.0);
+            if (__all(done)) break;
+            for (int r = 0; r < 15; ++r) {
+                int p, q;
+                if (t == 0) {
+                    p = r;
+                    q = 15;
+                } else {
+                    const int x = (r + t) % 15, y = (r - t + 15) % 15;
+                    p = min(x, y);
+                    q = max(x, y);
+                }
+                const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
+                double cc = 1.0, ss = 0.0;
+                if (apq != 0.0 && !done) {
+                    // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)) with theta = alpha / apq, written without forming theta:
+                    // t = sgn(alpha) apq / (|alpha| + hypot(alpha, apq))  -- one division and one square root fewer
+                    const double alpha = 0.5 * (aqq - app);
+                    const double rr = sqrt(alpha * alpha + apq * apq);
+                    const double tt = (alpha >= 0.0 ? apq : -apq) / (fabs(alpha) + rr);
+                    cc = 1.0 / sqrt(tt * tt + 1.0);
+                    ss = tt * cc;
+                }
+                if ((l & 1) == 0) {
+                    CS[rs][t][0] = cc;
+                    CS[rs][t][1] = ss;
+                }
+                wave_sync();
+                // column phase: lane l rotates row l's entries (p_i, q_i) for all 8 pairs
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int pi, qi;
+                    if (i == 0) { pi = r; qi = 15; } else {
+                        const int x = (r + i) % 15, y = (r - i + 15) % 15;
+                        pi = min(x, y); qi = max(x, y);
+                    }
+                    const double ci = CS[rs][i][0], si = CS[rs][i][1];
+                    const double akp = A[l][pi], akq = A[l][qi];
+                    A[l][pi] = ci * akp - si * akq;
+                    A[l][qi] = si * akp + ci * akq;
+                    const double ekp = E[l][pi], ekq = E[l][qi];
+                    E[l][pi] = ci * ekp - si * ekq;
+                    E[l][qi] = si * ekp + ci * ekq;
+                }
+                wave_sync();
+                // row phase: lane l rotates column l's entries of rows (p_i, q_i)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int pi, qi;
+                    if (i == 0) { pi = r; qi = 15; } else {
+                        const int x = (r + i) % 15, y = (r - i + 15) % 15;
+                        pi = min(x, y); qi = max(x, y);
+                    }
+                    const double ci = CS[rs][i][0], si = CS[rs][i][1];
+                    const double apk = A[pi][l], aqk = A[qi][l];
+                    A[pi][l] = ci * apk - si * aqk;
+                    A[qi][l] = si * apk + ci * aqk;
+                }
+                wave_sync();
+            }
+        }
+
+        // ---- minimum-norm solution: x = sum_k [|lam_k| > rcond * lam_max] (e_k . b / lam_k) e_k ----
+        const double lam = A[l][l];
+        const double lmax = row16_max(fabs(lam));
+        Coef[rs][l] = bl;
+        wave_sync();
+        double proj = 0.0;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) proj += E[a][l] * Coef[rs][a];
+        wave_sync();
+        const bool keep = fabs(lam) > rcond * lmax;
+        Coef[rs][l] = keep ? proj / lam : 0.0;
+        wave_sync();
+        x = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x += E[l][k] * Coef[rs][k];
+    }
     const float tl = (float)x;
     if (row < m && l < V) T_out[(int64_t)row * V + l] = tl;
 
