@@ -282,11 +282,7 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 #define GANQ_JACOBI_SWEEPS 30
 #endif
 constexpr int JS = 17;
-#ifdef GANQ_T_NO_FAST_SOLVE  // A/B switch: always the Jacobi eigen-solve
-constexpr bool kNoFastSolve = true;
-#else
-constexpr bool kNoFastSolve = false;
-#endif  // padded leading dimension of the fp64 16x16 matrices in LDS
+  // padded leading dimension of the fp64 16x16 matrices in LDS
 
 __device__ __forceinline__ double row16_sum(double x) {
     x += __shfl_xor(x, 1, 16);
@@ -667,7 +663,7 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
                                                      int n, int V, double rcond, float* __restrict__ T_out,
                                                      float* __restrict__ A_out, float* __restrict__ b_out,
                                                      double* __restrict__ loss_rows, int nparts,
-                                                     long long* __restrict__ changed_reset) {
+                                                     long long* __restrict__ changed_reset, int allow_fast) {
     // the change counter of this iteration has been consumed by the kernels in front of this one: leave it zero for
     // the next iteration's q_diff_kernel (saves a memset launch per iteration)
     if (changed_reset && blockIdx.x == 0 && threadIdx.x == 0) *changed_reset = 0;
@@ -775,7 +771,7 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     //      pivot or a large inverse take the Jacobi path below, and so does the whole wave then.
     double x = 0.0;
     bool fast = false;
-    if (!kNoFastSolve) {
+    if (allow_fast) {
         double r[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) r[a] = (l < V && a < V) ? colA[a] : ((a == l) ? 1.0 : 0.0);  // A[l][a] (symmetric)
@@ -1212,18 +1208,20 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
     {
         ProfScope prof(KID_T_SOLVE, stream);
         const dim3 grid((unsigned)((m + 3) / 4));
+        const char* env_jac = getenv("GANQ_T_JACOBI");  // test hook: 1 -> every row by the Jacobi eigen-solve
+        const int allow_fast = !(env_jac && env_jac[0] == '1');
         const long long* msrc = stateful ? mstate : mpart;
         const int nparts = stateful ? 0 : NP;  // 0: one part that is already symmetric
         if (WH32) {
             hipLaunchKernelGGL(t_solve_kernel<float>, grid, dim3(64), 0, stream, msrc, prep, hdiag, WH32,
                                static_cast<const double*>(nullptr), Q, (int)m, (int)n, V, rcond, T_out, A_out, b_out,
-                               static_cast<double*>(nullptr), nparts, static_cast<long long*>(nullptr));
+                               static_cast<double*>(nullptr), nparts, static_cast<long long*>(nullptr), allow_fast);
         } else {
             const double* WH64 = reinterpret_cast<const double*>(ws + lo.off_wh64);
             const double* wHw = reinterpret_cast<const double*>(ws + lo.off_whw);
             double* loss_rows = reinterpret_cast<double*>(ws + lo.off_lossrows);
             hipLaunchKernelGGL(t_solve_kernel<double>, grid, dim3(64), 0, stream, msrc, prep, hdiag, WH64, wHw, Q, (int)m,
-                               (int)n, V, rcond, T_out, A_out, b_out, loss_mode ? loss_rows : nullptr, nparts, changed);
+                               (int)n, V, rcond, T_out, A_out, b_out, loss_mode ? loss_rows : nullptr, nparts, changed, allow_fast);
             if (loss_mode == 2) hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, loss_rows, (int)m, loss_out);
         }
     }

@@ -273,6 +273,25 @@ def test_run_layer_incremental_many_changes(hip, monkeypatch):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
+@pytest.mark.parametrize("m,n,V", [(256, 1024, 16), (64, 512, 8), (37, 300, 4)])
+def test_update_t_cholesky_path_equals_jacobi_path(hip, oracle, m, n, V, monkeypatch):
+    # rows whose A is provably above the gelsd cut-off are solved by Cholesky; forcing the eigen-solve for every row
+    # must give the same codebook (both solve the same fp32-rounded system in fp64)
+    W, H, L, T0 = synth(m, n, V, seed=m + V, corr=0.3)
+    Q = oracle.solve_s(W, L, T0)
+    Q[3, :] = Q[3, :] % (V - 1)  # one row with an unused code: singular A, takes the eigen-solve in both runs
+    WH = oracle.matmul(W, H)
+    outs = []
+    for jac in ("0", "1"):
+        monkeypatch.setenv("GANQ_T_JACOBI", jac)
+        outs.append(hip.update_t(dev(WH), dev(H), dev(Q.astype(np.uint8)), V).cpu().numpy())
+    monkeypatch.delenv("GANQ_T_JACOBI")
+    assert rel_fro(outs[0], outs[1]) < 1e-9
+    assert (outs[0] == outs[1]).mean() > 0.98  # identical floats but for a rare last-bit rounding of the fp64 result
+    To = oracle.update_t(WH, H, Q, V)
+    assert rel_fro(outs[0], To) < TOL_T
+
+
 def test_reciprocal_quotient_equals_ieee_division(hip):
     # the S-solve replaces r / L[j][j] by a reciprocal-based sequence that must round like the division
     bad, first = hip.debug_div_check(1 << 30, seed=7)
