@@ -328,12 +328,18 @@ __global__ __launch_bounds__(256) void m_reduce_kernel(const long long* __restri
 }
 
 // one wave per row: columns whose index differs from the previous iteration -> chg[row][0..cnt), chgcnt[row]; *changed += cnt
-__global__ __launch_bounds__(256) void q_diff_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ Qprev, int m, int n,
+constexpr int QD_WAVES = 16;  // rows per workgroup: one add to the global change counter per workgroup -- one per row
+                              // made 4096 same-address atomics the longest part of the kernel (55 us)
+__global__ __launch_bounds__(QD_WAVES * 64) void q_diff_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ Qprev, int m, int n,
                                                     uint16_t* __restrict__ chg, int* __restrict__ chgcnt,
                                                     long long* __restrict__ changed) {
+    __shared__ int wg_total;
+    if (threadIdx.x == 0) wg_total = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= m) return;
+    const int row_raw = blockIdx.x * QD_WAVES + (threadIdx.x >> 6);
+    const bool active = row_raw < m;
+    const int row = active ? row_raw : m - 1;  // a padding wave repeats the last row and writes nothing
     const uint8_t* q = Q + (int64_t)row * n;
     const uint8_t* qp = Qprev + (int64_t)row * n;
     uint16_t* out = chg + (int64_t)row * n;
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256) void q_diff_kernel(const uint8_t* __restrict__
                     for (int by = 0; by < 4; ++by) {
                         const bool d = ((dw[w] >> (8 * by)) & 0xffu) != 0;
                         const unsigned long long mk = __ballot(d);
-                        if (d) out[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)(16 * i + 4 * w + by);
+                        if (d && active) out[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)(16 * i + 4 * w + by);
                         cnt += __popcll(mk);
                     }
             }
@@ -371,13 +377,15 @@ __global__ __launch_bounds__(256) void q_diff_kernel(const uint8_t* __restrict__
         const int x = x0 + lane;
         const bool d = x < n && q[x] != qp[x];
         const unsigned long long mk = __ballot(d);
-        if (d) out[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)x;
+        if (d && active) out[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)x;
         cnt += __popcll(mk);
     }
-    if (lane == 0) {
+    if (lane == 0 && active) {
         chgcnt[row] = cnt;
-        if (cnt) atomicAdd(reinterpret_cast<unsigned long long*>(changed), (unsigned long long)cnt);
+        if (cnt) atomicAdd(&wg_total, cnt);
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_total) atomicAdd(reinterpret_cast<unsigned long long*>(changed), (unsigned long long)wg_total);
 }
 
 // One workgroup per row, its waves share out the changed columns.  Column c = list[e] goes a_old -> a_new.  Taking the
@@ -1151,7 +1159,7 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
     if (stateful && iter > 0) {
         ProfScope prof(KID_T_INCR, stream);
         uint16_t* chg = reinterpret_cast<uint16_t*>(ws + lo.off_chg);
-        hipLaunchKernelGGL(q_diff_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, Q, qprev, (int)m, (int)n, chg, chgcnt,
+        hipLaunchKernelGGL(q_diff_kernel, dim3((unsigned)((m + QD_WAVES - 1) / QD_WAVES)), dim3(QD_WAVES * 64), 0, stream, Q, qprev, (int)m, (int)n, chg, chgcnt,
                            changed);
         const size_t usmem = (size_t)(256 + MU_WAVES * 16 * 64) * sizeof(long long) + align_up((size_t)n, 16);
         static size_t attr_usmem = 0;
