@@ -47,11 +47,21 @@ struct TPrep {              // device-side header written by t_prepare
 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ H, int64_t total, TPrep* __restrict__ prep) {
+    __shared__ unsigned int wmax[4];
     unsigned int mx = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
-        mx = max(mx, __builtin_bit_cast(unsigned int, H[i]) & 0x7fffffffu);  // |x| bits order like the values
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(H) & 15) == 0 ? (total >> 2) : 0;  // 16-byte loads when aligned
+    const uint4* H4 = reinterpret_cast<const uint4*>(H);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = H4[i];  // |x| bits order like the values
+        mx = max(max(mx, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        mx = max(mx, __builtin_bit_cast(unsigned int, H[i]) & 0x7fffffffu);
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(&prep->absmax_bits, mx);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    // one atomic per workgroup: thousands of same-address atomics were most of this kernel's time
+    if (threadIdx.x == 0) atomicMax(&prep->absmax_bits, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
 }
 
 __global__ void prep_scale_kernel(TPrep* prep) {
@@ -1109,7 +1119,7 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
     double* H64 = (with_f64 && lo.off_h64) ? reinterpret_cast<double*>(ws + lo.off_h64) : nullptr;
     ProfScope prof(KID_T_PREP, stream);
     GANQ_HIP_CHECK(hipMemsetAsync(prep, 0, sizeof(TPrep), stream));
-    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, stream, H, n * n, prep);
+    hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, H, n * n, prep);
     hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(1), 0, stream, prep);
     const int64_t quads = n * lo.nq / 4;
     int* Hint = with_f64 ? reinterpret_cast<int*>(ws + lo.off_hint) : nullptr;
