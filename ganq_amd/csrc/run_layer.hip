@@ -145,12 +145,20 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
 
     rc = solve_s_pack_l(L, ldl, m, n, ws + lo.off_solve, stream);  // L is the same in every iteration
     if (rc) return rc;
+    // rows whose indices did not change in an iteration are fixed points (same indices -> same bucket sums -> same
+    // codebook -> same indices): from the next S-solve on they are skipped
+    const int* rowlist = nullptr;
+    const int* nactive = nullptr;
     for (int k = 0; k < K; ++k) {
-        rc = solve_s_launch(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, stream);
+        rc = solve_s_launch(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, stream, rowlist, nactive);
         if (rc) return rc;
         // new codebook and, from the same A and b, the loss of (new codebook, these indices)  (ganq.py:589-591, :621-622)
         rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, 1, nullptr, k, stream);
         if (rc) return rc;
+        if (k >= 1 && k + 1 < K) {
+            rc = t_active_rows(m, lo.t, ws + lo.off_upd, &rowlist, &nactive, stream);
+            if (rc) return rc;
+        }
         std::swap(Tc, Tn);
         {
             const int64_t words = m * V;  // fp32 codebook

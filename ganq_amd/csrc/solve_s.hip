@@ -163,7 +163,8 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                                                       int64_t ldl, const float* __restrict__ Lr, int NT,
                                                       const float* __restrict__ T, int m, int n, int V,
                                                       uint8_t* __restrict__ Q, float* __restrict__ ErrOut,
-                                                      float* __restrict__ ErrT, int pbase) {
+                                                      float* __restrict__ ErrT, int pbase, const int* __restrict__ rowlist,
+                                                      const int* __restrict__ nactive) {
     __shared__ float4 Ld[2][SB][16];      // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
     __shared__ float Rp[2][SR][SB + 4];   // residual panel handed from (G) to (P)
     __shared__ float2 Dg[2][SB];          // {L[j][j], 1 / L[j][j]} of the panel's columns
@@ -180,8 +181,13 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
     const int rsub = lane >> 4;
     const int c16 = lane & 15;
     const int prow_in_tile = 4 * gw + rsub;  // row handled by this 16-lane group in phase (P)
-    const int prow = min(tile * SR + prow_in_tile, m - 1);
-    const bool prow_ok = tile * SR + prow_in_tile < m;
+    // rowlist / nactive (device, may be null): solve only these rows (the loop driver passes the rows that have not
+    // reached their fixed point yet); tile t then holds rows rowlist[16 t .. 16 t + 15]
+    const int nact = nactive ? *nactive : m;
+    if (tile * SR >= nact) return;  // uniform for the workgroup, before any barrier
+    const int slot = tile * SR + prow_in_tile;
+    const bool prow_ok = slot < nact;
+    const int prow = rowlist ? rowlist[min(slot, nact - 1)] : min(slot, m - 1);
     const int nb = (n + SB - 1) / SB;
     float* __restrict__ errt = ErrT + (int64_t)tile * nb * 1024;
 
@@ -413,7 +419,7 @@ int solve_s_pack_l(const float* L, int64_t ldl, int64_t m, int64_t n, void* work
 
 // the solve proper; the workspace already holds the packed L
 int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, int64_t m, int64_t n, int V, uint8_t* Q_out,
-                   float* Err_out, void* workspace, hipStream_t stream) {
+                   float* Err_out, void* workspace, hipStream_t stream, const int* rowlist, const int* nactive) {
     const SolveLayout lo = solve_layout(m, n);
     float* errt = static_cast<float*>(workspace);
     const float* Lr = reinterpret_cast<const float*>(static_cast<char*>(workspace) + lo.errt_bytes);
@@ -432,10 +438,10 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
     ProfScope prof(KID_SOLVE_S, stream);
     if (mfma_k_ascending()) {
         hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
-                           V, Q_out, Err_out, errt, pbase);
+                           V, Q_out, Err_out, errt, pbase, rowlist, nactive);
     } else {
         hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
-                           V, Q_out, Err_out, errt, pbase);
+                           V, Q_out, Err_out, errt, pbase, rowlist, nactive);
     }
     GANQ_LAUNCH_CHECK();
     return 0;

@@ -11,6 +11,7 @@ struct TLayout {
     size_t off_hint, off_qprev, off_mstate, off_chg, off_chgcnt;
     // split-fp16 W @ H_fixed (wh_gemm.hip): packed pieces of W and H, row exponents, Wlo flags
     size_t off_wp, off_hp, off_rexp, off_wlo;
+    size_t off_active;  // rows that changed in the last iteration (S-solve work list)
 };
 
 TLayout t_layout(int64_t m, int64_t n, bool with_f64);
@@ -28,6 +29,10 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
 // (exact: the sums are integers), falling back to the full accumulation on the device when too many changed.
 int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
               float* T_out, float* A_out, float* b_out, int loss_mode, double* loss_out, int iter, hipStream_t stream);
+
+// after t_iterate(iter >= 1): rows whose indices changed in that iteration (device list + count; both null when
+// there are no change lists).  Unchanged rows are fixed points of the alternation and need no further S-solve.
+int t_active_rows(int64_t m, const TLayout& lo, char* ws, const int** list, const int** count, hipStream_t stream);
 
 inline const double* t_loss_rows(const TLayout& lo, const char* ws) { return reinterpret_cast<const double*>(ws + lo.off_lossrows); }
 

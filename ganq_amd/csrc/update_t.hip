@@ -786,7 +786,8 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     //      from its Cholesky factor), nothing is cut off and the minimum-norm solution is simply A^-1 b.  Then
     //      t = L^-T (L^-1 b) needs 16 pivots instead of ~60 Jacobi rounds.  All in registers: lane l owns row l of L and
     //      column l of L^-1, values travel by 16-lane shuffles.  Rows with an unused code (a zero pivot), a tiny
-    //      pivot or a large inverse take the Jacobi path below, and so does the whole wave then.
+    //      pivot or a large inverse take the Jacobi path below (the other rows of their wave walk through it with them and
+    //      keep their own result).
     double x = 0.0;
     bool fast = false;
     if (allow_fast) {
@@ -827,10 +828,11 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
         }
         const double inv_norm2 = row16_sum(l < V ? n2 : 0.0);     // ||L^-1||_F^2 >= 1 / sigma_min(A)
         const double tr = row16_sum(l < V ? colA[l] : 0.0);       // trace(A) >= sigma_max(A)
-        const bool row_ok = ok && (4.0 * rcond * tr * inv_norm2 < 1.0);  // false for NaN
-        fast = __all(row_ok);
+        fast = ok && (4.0 * rcond * tr * inv_norm2 < 1.0);  // false for NaN; decided per row: a row's result must not
+                                                             // depend on which rows share its wave
     }
-    if (!fast) {
+    const double x_fast = x;
+    if (!__all(fast)) {
         // ---- round-robin Jacobi: 15 rounds of 8 disjoint rotations per sweep ----
         const int t = l >> 1;  // pair handled (redundantly) by lanes 2t, 2t+1
         for (int sweep = 0; sweep < GANQ_JACOBI_SWEEPS; ++sweep) {
@@ -922,6 +924,7 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
 #pragma unroll
         for (int k = 0; k < 16; ++k) x += E[l][k] * Coef[rs][k];
     }
+    if (fast) x = x_fast;
     const float tl = (float)x;
     if (row < m && l < V) T_out[(int64_t)row * V + l] = tl;
 
@@ -1081,12 +1084,14 @@ TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
     lo.off_h64 = lo.off_wh64 = lo.off_whw = lo.off_lossrows = 0;
     lo.off_hint = lo.off_qprev = lo.off_mstate = lo.off_chg = lo.off_chgcnt = 0;
     lo.off_wp = lo.off_hp = lo.off_rexp = lo.off_wlo = 0;
+    lo.off_active = 0;
     if (with_f64) {
         lo.off_hint = take((size_t)n * n * sizeof(int));
         lo.off_qprev = take((size_t)m * n);
         lo.off_mstate = take((size_t)m * 256 * sizeof(long long));
         lo.off_chg = take((size_t)m * n * sizeof(uint16_t));
         lo.off_chgcnt = take((size_t)m * sizeof(int) + 64);  // counts per row, then the 8-byte total
+        lo.off_active = take(((size_t)m + 1) * sizeof(int));  // rows that changed in the last iteration, their number
         if (wh_use_f64_gemm()) {
             lo.off_h64 = take((size_t)n * n * sizeof(double));
         } else {
@@ -1108,6 +1113,35 @@ __global__ __launch_bounds__(256) void hfixed_kernel(const int* __restrict__ Hin
                                                     double* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
         out[i] = prep->scale * (double)Hint[i];
+}
+
+// rows whose indices changed in this iteration (ascending) and their number.  A row without a change has reached a
+// fixed point: its bucket sums, hence its codebook, hence its next indices repeat -- the S-solve skips it from now on.
+__global__ __launch_bounds__(1024) void active_rows_kernel(const int* __restrict__ chgcnt, int m, int* __restrict__ list,
+                                                           int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int carry_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_sh = 0;
+    __syncthreads();
+    for (int base = 0; base < m; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < m && chgcnt[i] > 0) ? 1 : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int before = carry_sh;
+        for (int k = 0; k < wv; ++k) before += wsum[k];
+        if (v) list[before + incl - 1] = i;
+        __syncthreads();
+        if (tid == 1023) carry_sh = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *count = carry_sh;
 }
 
 // once per layer: fixed-point planes of H (+ optionally W @ H_fixed in fp64 and w^T H w per row)
@@ -1244,6 +1278,23 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         }
     }
     GANQ_LAUNCH_CHECK();
+    return 0;
+}
+
+// after t_iterate(iter >= 1): device list / count of the rows that changed in that iteration (null when the bucket sums
+// are not kept between iterations, i.e. no change lists exist)
+int t_active_rows(int64_t m, const TLayout& lo, char* ws, const int** list, const int** count, hipStream_t stream) {
+    *list = nullptr;
+    *count = nullptr;
+    const char* env_full = getenv("GANQ_T_FULL");
+    const char* env_all = getenv("GANQ_SOLVE_ALL_ROWS");  // test hook: never skip a row in the S-solve
+    if (lo.off_hint == 0 || lo.off_active == 0 || (env_full && env_full[0] == '1') || (env_all && env_all[0] == '1')) return 0;
+    int* l = reinterpret_cast<int*>(ws + lo.off_active);
+    int* c = l + m;
+    hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const int*>(ws + lo.off_chgcnt), (int)m, l, c);
+    GANQ_LAUNCH_CHECK();
+    *list = l;
+    *count = c;
     return 0;
 }
 
