@@ -35,7 +35,8 @@ def find_modules(layer: nn.Module, names: Sequence[str]) -> Dict[str, nn.Module]
 
 class ModuleLooper:
     def __init__(self, processor, layers: Sequence[nn.Module], layer_modules: List[List[str]],
-                 layers_prefix: str = "model.layers", share_group_hessian: bool = False, early_exit: bool = True):
+                 layers_prefix: str = "model.layers", share_group_hessian: bool = False, early_exit: bool = True,
+                 cache_outputs: bool = True, cache_budget_bytes: int = 48 << 30):
         # share_group_hessian: the modules of one group ([q,k,v], [gate,up]) receive the same inputs, so the first
         # one accumulates the Hessian and runs the prologue (permutation, factor, damping) for all of them; the
         # reference does both once per module.  Same numbers, less work.  Only valid when the groups really share
@@ -47,6 +48,12 @@ class ModuleLooper:
         # the output); same statistics, about a third less forward work per layer.  Turn it off for a layer that calls
         # one of its Linear modules more than once per forward.
         self.early_exit = early_exit
+        # cache_outputs: once a module is quantized its weights are final, and (the groups being in forward order) so
+        # are its inputs: the later passes over the same layer reuse its per-batch outputs instead of recomputing the
+        # GEMM.  Same tensors, about a third less forward work again; the outputs of one layer stay on the device until
+        # the layer is done (up to cache_budget_bytes).  Turn it off together with early_exit for unusual layers.
+        self.cache_outputs = cache_outputs
+        self.cache_budget_bytes = int(cache_budget_bytes)
         self.processor = processor
         self.layers = layers
         self.layer_modules = layer_modules
@@ -62,6 +69,26 @@ class ModuleLooper:
         fwd = forward or (lambda layer, x, kw: layer(x, **kw))
         dist = gdist.Dist.current()
         for li, layer in enumerate(self.layers):
+            cur = {"batch": 0}
+            wrapped, cached_bytes = [], [0]
+
+            def cache_module(mod):
+                store = [None] * len(layer_inputs)
+                orig = mod.forward
+
+                def forward_cached(*a, **k):
+                    b = cur["batch"]
+                    y = store[b]
+                    if y is None:
+                        y = orig(*a, **k)
+                        if isinstance(y, torch.Tensor) and cached_bytes[0] + y.numel() * y.element_size() <= self.cache_budget_bytes:
+                            store[b] = y
+                            cached_bytes[0] += y.numel() * y.element_size()
+                    return y
+
+                mod.forward = forward_cached  # instance attribute: shadows the class method until it is deleted
+                wrapped.append(mod)
+
             for names in self.layer_modules:
                 mods = find_modules(layer, names)
                 if not mods:
@@ -96,8 +123,9 @@ class ModuleLooper:
                     handles += [mods[n].register_forward_hook(stop_hook) for n in mine
                                 if not self.processor.is_skipped(named[n])
                                 and getattr(self.processor.tasks[n], "_group_leader", None) is None]
-                for x, kw in zip(layer_inputs, layer_kwargs):
+                for bi, (x, kw) in enumerate(zip(layer_inputs, layer_kwargs)):
                     fired.clear()
+                    cur["batch"] = bi
                     try:
                         fwd(layer, x, kw)
                     except _StopForward:
@@ -119,14 +147,21 @@ class ModuleLooper:
                         self.processor.skip(named[n])
                         continue
                     self.processor.process(named[n])
+                    if self.cache_outputs:
+                        cache_module(mods[n])
                     if progress:
                         progress(named[n])
                 if dist.world > 1:
                     for n in named:  # owner broadcasts its result so every rank holds the quantized group
                         gdist.share_module_result(self.processor, named[n], owners[n], dist)
+                        if self.cache_outputs and n not in mine:
+                            cache_module(mods[n])
             outs = []
-            for x, kw in zip(layer_inputs, layer_kwargs):
+            for bi, (x, kw) in enumerate(zip(layer_inputs, layer_kwargs)):
+                cur["batch"] = bi
                 y = fwd(layer, x, kw)
                 outs.append(y[0] if isinstance(y, (tuple, list)) else y)
+            for mod in wrapped:
+                del mod.forward  # back to the class method; the cached outputs go with the closure
             layer_inputs = outs
         return layer_inputs

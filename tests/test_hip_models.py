@@ -70,8 +70,16 @@ def test_quantize_model_other_families(kind):
     proc = quantize_model(model, calib, qcfg)
     assert len(proc.results()) == 2 * per_layer
     assert sum(isinstance(mod, GanqHipQuantLinear) for mod in model.modules()) == 2 * per_layer
+    # the FORMAT.FAKE run uses the plain looper of the reference (whole layer forward in every pass, nothing cached):
+    # the shortcuts of the default looper must not change a single weight
     quantize_model(fake, calib, QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2,
-                                               format="fake"))
+                                               format="fake"), early_exit=False, cache_outputs=False)
+    fake_mods = dict(fake.named_modules())
+    for name, mod in model.named_modules():
+        if isinstance(mod, GanqHipQuantLinear):
+            w = fake_mods[name].weight.data
+            w = w.t() if type(fake_mods[name]).__name__ == "Conv1D" else w
+            assert torch.equal(mod.dequantize_weight(), w), name
     x = calib[0][:1].cuda()
     a, b = model(x).logits.float(), fake(x).logits.float()
     assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=3e-2, atol=3e-2)
