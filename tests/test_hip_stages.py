@@ -228,6 +228,23 @@ def test_run_layer_vs_oracle(hip, oracle, m, n, V, K, seed):
     assert rel_fro(T.cpu().numpy(), To) < 1e-3 if frac > 0 else rel_fro(T.cpu().numpy(), To) < TOL_T
 
 
+@pytest.mark.parametrize("half_w", [True, False])
+def test_run_layer_ten_iterations_vs_oracle(hip, oracle, half_w):
+    # K = 10 as in the benchmark: rows converge and are skipped by the later S-solves, the codebooks come from the
+    # Cholesky fast path, W @ H from the split-fp16 product (fp16-valued weights skip its third term) -- the indices of
+    # the last iteration, the best codebook and every distance must still be the oracle's
+    m, n, V, K = 80, 2048, 16, 10
+    W, H, L, T0 = synth(m, n, V, 91, corr=0.15)
+    if half_w:
+        W = W.astype(np.float16).astype(np.float32)
+    To, Qo, do, bko = oracle.run_layer(W, H, L, T0, K, alias_q=True)
+    T, Q, d, bk = hip.run_layer(dev(W), dev(H), dev(L), dev(T0), K, alias_q=True)
+    assert int(bk) == bko
+    assert np.allclose(d.cpu().numpy(), do, rtol=1e-6)
+    assert np.array_equal(Q.cpu().numpy(), Qo)
+    assert rel_fro(T.cpu().numpy(), To) < TOL_T
+
+
 @pytest.mark.parametrize("m,n,V,K,seed", [(96, 1024, 16, 6, 41), (40, 777, 8, 5, 42), (33, 250, 4, 4, 43), (64, 4112, 16, 3, 44)])
 def test_run_layer_incremental_equals_full(hip, m, n, V, K, seed, monkeypatch):
     # the loop keeps the integer bucket sums between iterations and only moves the entries of changed indices;
