@@ -298,23 +298,29 @@ struct Lookahead {
     hipStream_t side;
     hipEvent_t col_done, rest_done;
 };
-// one helper stream + two events per device, created on first use (GANQ_CHOL_LOOKAHEAD=0 turns the second stream off)
-Lookahead* lookahead_for_current_device() {
-    static Lookahead slots[64];
-    static bool made[64] = {};
+// one helper stream + two events per (device, caller stream), created on first use: two factorisations may run at
+// the same time on different streams (the prologue does that).  GANQ_CHOL_LOOKAHEAD=0 turns the second stream off.
+Lookahead* lookahead_for(hipStream_t main) {
+    struct Slot {
+        int dev;
+        hipStream_t main;
+        Lookahead la;
+    };
+    static Slot slots[32];
+    static int used = 0;
     static const bool off = [] { const char* e = getenv("GANQ_CHOL_LOOKAHEAD"); return e && e[0] == '0'; }();
     int dev = 0;
-    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!made[dev]) {
-        Lookahead la{};
-        if (hipStreamCreateWithFlags(&la.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&la.col_done, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&la.rest_done, hipEventDisableTiming) != hipSuccess)
-            return nullptr;
-        slots[dev] = la;
-        made[dev] = true;
-    }
-    return &slots[dev];
+    if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (int i = 0; i < used; ++i)
+        if (slots[i].dev == dev && slots[i].main == main) return &slots[i].la;
+    if (used == 32) return nullptr;  // more caller streams than slots: plain single-stream factorisation
+    Lookahead la{};
+    if (hipStreamCreateWithFlags(&la.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&la.col_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&la.rest_done, hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+    slots[used] = Slot{dev, main, la};
+    return &slots[used++].la;
 }
 }  // namespace
 
@@ -348,7 +354,7 @@ extern "C" int ganq_cholesky(float* A, int64_t n, int64_t lda, int32_t* info_out
     // Look-ahead: the diagonal block and the panel of step j+1 only need the first block column of step j's trailing
     // update.  That column is updated first; the rest of the update runs on a second stream next to the (single
     // workgroup, latency-bound) diagonal kernel and the panel kernel of the next step.
-    Lookahead* la = lookahead_for_current_device();
+    Lookahead* la = lookahead_for(stream);
     // measured on MI355X: n = 2048 1.97 ms with / 1.84 without, 4096 4.05 / 4.14, 8192 11.6 / 13.0 (the two event hops
     // per step cost about as much as the overlap gains below n = 4096)
     const bool two = la != nullptr && n >= 32 * CB;

@@ -24,6 +24,17 @@ from .config import QuantizeConfig
 from .quantizer import HF_OPTIMUM, Quantizer
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """one extra stream per device for the part of the prologue that runs beside the main stream"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _SIDE_STREAMS[idx]
+
+
 def _is_conv1d(module) -> bool:
     return type(module).__name__ == "Conv1D"  # transformers.pytorch_utils.Conv1D, without importing transformers
 
@@ -192,9 +203,23 @@ class GPTQ:
             # the GANQ loop only reads diag(Hinv), which one factorisation of the index-reversed matrix gives (config.py)
             native = (getattr(self.qcfg, "ganq_prologue", "torch") == "hip" and self._needs_only_hinv_diag() and H.is_cuda)
             chol = self._hip_cholesky if native else torch.linalg.cholesky
+            pending = None  # (factor, info, stream) of a factorisation running beside the main stream
             if self.qcfg.l_damp_style == "ganq":
                 offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
-                self.L = chol(H + torch.diag(offset))
+                if native:
+                    # the two factorisations of the prologue (this one and the one that yields diag(Hinv)) are
+                    # independent chains of small kernels: run this one on a second stream, beside the other
+                    from .. import _lib
+                    A1 = H + torch.diag(offset)
+                    cur, side = torch.cuda.current_stream(H.device), _side_stream(H.device)
+                    side.wait_stream(cur)
+                    A1.record_stream(side)
+                    with torch.cuda.stream(side):
+                        L1, info1 = _lib.cholesky(A1, check=False)
+                    L1.record_stream(cur)
+                    pending = (L1, info1, side)
+                else:
+                    self.L = chol(H + torch.diag(offset))
 
             damp_percent = self.qcfg.damp_percent
             Hinv = None
@@ -220,6 +245,13 @@ class GPTQ:
                         damp_percent += self.qcfg.damp_auto_increment
                     else:
                         raise e
+            if pending is not None:
+                L1, info1, side = pending
+                torch.cuda.current_stream(H.device).wait_stream(side)
+                if int(info1):
+                    raise torch.linalg.LinAlgError("ganq_cholesky: H + diag(offset) is not positive-definite "
+                                                   f"(leading minor of order {int(info1)})")
+                self.L = L1
             if not (0 < damp_percent < 1):
                 raise ValueError(f"Quantization: `damp_percent` must between 0 and 1. current is {damp_percent}")
             followers = getattr(self, "_followers", [])
