@@ -26,11 +26,22 @@
 
 namespace ganq {
 
-constexpr int TR = 32;          // rows of W per workgroup
-constexpr int TW = 8;           // waves per workgroup
+// tile shape of onehot_accum_kernel (overridable for experiments).  Measured on MI355X, 4096x4096: (waves, u per tile) =
+// (8, 256) 2.25 ms, (8, 128) 2.31, (4, 256) 3.44, (4, 128) 3.43 -- two smaller workgroups per CU lose more to the halved
+// reuse of each staged digit tile than they gain from overlapping each other's barriers
+#ifndef ACC_TW
+#define ACC_TW 8
+#endif
+#ifndef ACC_UT
+#define ACC_UT 256
+#endif
+constexpr int TW = ACC_TW;      // waves per workgroup
 constexpr int RW = 4;           // rows per wave
+constexpr int TR = TW * RW;     // rows of W per workgroup
 constexpr int VCH = 32;         // v columns per chunk (two 16-wide MFMA column tiles)
-constexpr int UT = 256;         // u per staged tile (four 64-deep MFMA steps)
+constexpr int UT = ACC_UT;      // u per staged tile (UT / 64 MFMA steps of 64)
+constexpr int KS64 = UT / 64;
+constexpr int UC16 = UT / 16;   // 16-byte pieces per tile row
 constexpr int NP = 8;           // chunk c belongs to part c % NP; every part writes one partial A
 constexpr int BROW = UT + 16;   // LDS row pitch of a digit tile in bytes (pad against bank conflicts)
 constexpr int BTILE = 4 * VCH * BROW;
@@ -157,12 +168,13 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
     for (int i = lane; i < RW * 256; i += 64) Mrow[wv][i >> 8][i & 255] = 0;
 
     // staging of one digit tile: 4 planes x VCH rows x 256 B = 2048 x 16 B, 4 per thread
-    uint4 stage[4];
+    constexpr int NE = 4 * VCH * UC16 / (TW * 64);  // 16-byte pieces of a digit tile per thread
+    uint4 stage[NE];
     auto gload = [&](int v0, int t) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = e * (TW * 64) + tid;  // 0..2047
-            const int c16 = idx & 15, vi = (idx >> 4) & (VCH - 1), p = idx >> 9;
+        for (int e = 0; e < NE; ++e) {
+            const int idx = e * (TW * 64) + tid;
+            const int c16 = idx % UC16, vi = (idx / UC16) & (VCH - 1), p = idx / (UC16 * VCH);
             const int v = v0 + vi, ub = t * UT + 16 * c16;
             uint4 x = make_uint4(0, 0, 0, 0);
             if (v < n && ub + 15 > v && ub < nq) {
@@ -182,9 +194,9 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int idx = e * (TW * 64) + tid;
-            const int c16 = idx & 15, vi = (idx >> 4) & (VCH - 1), p = idx >> 9;
+            const int c16 = idx % UC16, vi = (idx / UC16) & (VCH - 1), p = idx / (UC16 * VCH);
             *reinterpret_cast<uint4*>(Bbuf + buf * BTILE + (p * VCH + vi) * BROW + 16 * c16) = stage[e];
         }
     };
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 #pragma unroll
             for (int p = 0; p < RW / 2; ++p) dst[p] = gi < ng ? bits[((int64_t)mrow[p] * ng + gi) * 16 + a16] : 0ull;
         };
-        load_masks(t_first * 4, wb[0]);
+        load_masks(t_first * KS64, wb[0]);
         { const long long tt = __builtin_amdgcn_s_memtime(); st_pro += tt - st_t0; st_t0 = tt; }
         for (int t = t_first; t < ntile; ++t) {
             const int buf = (t - t_first) & 1;
@@ -228,12 +240,12 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
             v4i bf[2][4];
             read_b(0, 0, bf[0]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                load_masks(t * 4 + ks + 1, wb[(ks + 1) & 1]);  // next step (possibly of the next tile)
+            for (int ks = 0; ks < KS64; ++ks) {
+                load_masks(t * KS64 + ks + 1, wb[(ks + 1) & 1]);  // next step (possibly of the next tile)
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) {
                     const int hh = ks * 2 + kh;
-                    if (hh + 1 < 8) read_b((hh + 1) >> 1, (hh + 1) & 1, bf[(hh + 1) & 1]);  // next 32-column half
+                    if (hh + 1 < 2 * KS64) read_b((hh + 1) >> 1, (hh + 1) & 1, bf[(hh + 1) & 1]);  // next 32-column half
                     if (t * UT + ks * 64 + kh * 32 + 31 <= v0) continue;  // entirely on or above the diagonal (uniform)
 #pragma unroll
                     for (int p = 0; p < RW / 2; ++p) {
