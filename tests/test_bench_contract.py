@@ -1,0 +1,29 @@
+"""The one-line JSON bench.py prints (driver contract): checked on the newest committed run under profiles/."""
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest():
+    files = glob.glob(os.path.join(ROOT, "profiles", "r01_bench_v*.json"))
+    return max(files, key=lambda f: int(re.search(r"_v(\d+)\.json$", f).group(1)))
+
+
+def test_bench_line_has_the_contract_fields():
+    line = open(_latest()).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "columns/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # value = units all ranks processed / time: columns of the layer x steps / (steps x ms_per_step)
+    assert abs(d["value"] - d["n_gpus"] * d["config"]["n"] / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
