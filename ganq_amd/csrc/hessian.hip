@@ -19,7 +19,14 @@
 namespace ganq {
 
 constexpr int HT = 128;       // output tile edge
-constexpr int HK = 32;        // tokens per slab
+// tokens per slab (overridable for experiments).  Measured on MI355X, 2048 tokens: 32 -> 109 us at n = 4096, 326 us at
+// 8192; 64 -> 138 / 360 us: the kernel is bound by the latency of a workgroup's slab chain at 2 workgroups per CU
+// (528 tiles at n = 4096), longer slabs only lengthen the exposed part of each step
+#ifndef HESS_HK
+#define HESS_HK 32
+#endif
+constexpr int HK = HESS_HK;   // tokens per slab
+constexpr int HL = HK / 16;   // 16-byte loads per thread, operand and slab (256 threads x 16 B = 16 tokens x 128 features)
 constexpr int HP = HT + 8;    // LDS row pitch in 16-bit elements (272 B, multiple of 8 B)
 
 typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -66,15 +73,15 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
     // staging: slab = 32 tokens x 128 features = 512 x 16 B per operand, 2 per thread
     // four slabs of registers in rotation: the loads of slab s+3 are issued while slab s is multiplied (a slab's 64
     // MFMA-cycles are far shorter than one trip to L2 / HBM, and a tile is a chain of rows/32 such trips)
-    uint4 ra4[4][2], rb4[4][2];
+    uint4 ra4[4][HL], rb4[4][HL];
     // fast path (uniform per workgroup): full, 16-byte aligned tile columns -> unconditional loads (a token row past
     // the end is clamped and zeroed afterwards), so that the compiler can count the loads in flight instead of
     // draining them at every slab
     const bool fast = (u0 + HT <= n) && (v0 + HT <= n) && ((n & 7) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    auto gload = [&](auto fast_tag, int t0, uint4 (&ra)[2], uint4 (&rb)[2]) {
+    auto gload = [&](auto fast_tag, int t0, uint4 (&ra)[HL], uint4 (&rb)[HL]) {
         constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < HL; ++h) {
             const int idx = h * 256 + tid;
             const int t = t0 + (idx >> 4), f8 = (idx & 15) * 8;
             uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
@@ -98,9 +105,9 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
             rb[h] = vb;
         }
     };
-    auto sstore = [&](int buf, const uint4 (&ra)[2], const uint4 (&rb)[2]) {
+    auto sstore = [&](int buf, const uint4 (&ra)[HL], const uint4 (&rb)[HL]) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < HL; ++h) {
             const int idx = h * 256 + tid;
             const int t = idx >> 4, f8 = (idx & 15) * 8;
             *reinterpret_cast<uint4*>(&Xa[buf][t][f8]) = ra[h];
