@@ -69,15 +69,20 @@ class ModuleLooper:
         fwd = forward or (lambda layer, x, kw: layer(x, **kw))
         dist = gdist.Dist.current()
         for li, layer in enumerate(self.layers):
-            cur = {"batch": 0}
+            cur = {"batch": 0, "pass": 0}
             wrapped, cached_bytes = [], [0]
 
             def cache_module(mod):
                 store = [None] * len(layer_inputs)
+                served = [-1] * len(layer_inputs)
                 orig = mod.forward
 
                 def forward_cached(*a, **k):
                     b = cur["batch"]
+                    if served[b] == cur["pass"]:
+                        raise RuntimeError("ModuleLooper: a quantized module is called twice in one forward of its layer; "
+                                           "construct the looper with cache_outputs=False, early_exit=False")
+                    served[b] = cur["pass"]
                     y = store[b]
                     if y is None:
                         y = orig(*a, **k)
@@ -115,6 +120,9 @@ class ModuleLooper:
                 hooked, fired = len(handles), set()
                 if self.early_exit and hooked:
                     def stop_hook(mod, _inp, _out):
+                        if id(mod) in fired:
+                            raise RuntimeError("ModuleLooper: a module of the group is called twice in one forward of its "
+                                               "layer; construct the looper with early_exit=False, cache_outputs=False")
                         fired.add(id(mod))
                         if len(fired) == hooked:
                             raise _StopForward
@@ -126,6 +134,7 @@ class ModuleLooper:
                 for bi, (x, kw) in enumerate(zip(layer_inputs, layer_kwargs)):
                     fired.clear()
                     cur["batch"] = bi
+                    cur["pass"] += 1
                     try:
                         fwd(layer, x, kw)
                     except _StopForward:
@@ -159,6 +168,7 @@ class ModuleLooper:
             outs = []
             for bi, (x, kw) in enumerate(zip(layer_inputs, layer_kwargs)):
                 cur["batch"] = bi
+                cur["pass"] += 1
                 y = fwd(layer, x, kw)
                 outs.append(y[0] if isinstance(y, (tuple, list)) else y)
             for mod in wrapped:

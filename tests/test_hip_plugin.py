@@ -252,6 +252,36 @@ def test_looper_reports_modules_without_calibration_data():
     assert isinstance(model.layers[0].b, nn.Linear)
 
 
+@torch.no_grad()
+def test_looper_refuses_shortcuts_for_a_module_called_twice():
+    # early exit / output caching assume one call per module and layer forward; a layer that breaks this must be told
+    from ganq_amd.looper.gptq_processor import GPTQProcessor
+    from ganq_amd.looper.module_looper import ModuleLooper
+    from ganq_amd.quantization import QuantizeConfig
+
+    class Twice(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Linear(64, 64), nn.Linear(64, 64)
+
+        def forward(self, x):
+            return self.b(self.a(self.a(x)))  # self.a twice
+
+    def run(**kw):
+        torch.manual_seed(0)
+        model = nn.Module()
+        model.layers = nn.ModuleList([Twice()])
+        model = model.half().cuda()
+        xs = [torch.randn(2, 32, 64, device="cuda").half() for _ in range(2)]
+        proc = GPTQProcessor(QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=1))
+        ModuleLooper(proc, model.layers, [["a"], ["b"]], layers_prefix="layers", **kw).loop(xs)
+        return proc
+
+    with pytest.raises(RuntimeError, match="called twice"):
+        run()
+    assert len(run(early_exit=False, cache_outputs=False).results()) == 2  # the plain looper handles it like the reference
+
+
 @pytest.mark.parametrize("bits,rows", [(4, 1), (4, 40), (3, 7), (2, 16)])
 def test_quantlinear_pack_forward_and_state_dict(bits, rows):
     from ganq_amd.nn_modules.qlinear.ganq_hip import GanqHipQuantLinear
