@@ -5,7 +5,7 @@ missing, fails to load or lacks a symbol, importing a compute entry point raises
 ``GanqHipError`` -- loudly, by design.
 
 Tensors are torch-owned; this layer only borrows ``data_ptr()`` for the duration of a call
-and passes ``torch.cuda.current_stream().cuda_stream`` (reference boundary: the tensors that
+and passes the current torch stream of the tensors' device, with that device made current (reference boundary: the tensors that
 ``GANQ._perform_quantization_loop`` receives, gptqmodel/quantization/ganq.py:456).
 """
 import ctypes
@@ -53,6 +53,13 @@ SIGNATURES = {
     "ganq_run_layer": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_uint32, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
                                       _c_vp]),
+    "ganq_run_layer_rows": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_i64, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_uint32, ctypes.c_double, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
+                                           _c_vp, _c_sz, _c_vp]),
+    "ganq_select_best": (ctypes.c_int, [_c_vp, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_vp]),
+    "ganq_debug_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong]),
+    "ganq_debug_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]),
+    "ganq_debug_reset_option": (ctypes.c_int, [ctypes.c_char_p]),
     "ganq_lut_linear_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, ctypes.c_int]),
     "ganq_lut_linear_workspace_init": (ctypes.c_int, [_c_vp, _c_sz, _c_vp]),
     "ganq_lut_linear_fwd": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64,
@@ -123,8 +130,55 @@ def _check(rc: int, what: str):
         raise GanqHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    """hipStream_t of torch's current stream ON `device` (default: the current device)"""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on:
+    """Make the device of `t` the current HIP device for the duration of a library call: the library launches on the
+    current device (kernel attributes, probe results and helper streams are kept per device), and the stream handed
+    over must be that device's.  All tensors of a call must live on ONE device."""
+
+    def __init__(self, *tensors):
+        devs = {t.device for t in tensors if t is not None and hasattr(t, "device")}
+        if len(devs) != 1:
+            raise GanqHipError(f"all tensors of a call must live on one GPU, got {sorted(map(str, devs))}")
+        self.device = devs.pop()
+        if self.device.type != "cuda":
+            raise GanqHipError(f"tensors must live on the GPU (got {self.device}); the HIP path has no CPU fallback")
+        self._guard = torch.cuda.device(self.device)
+
+    def __enter__(self):
+        self._guard.__enter__()
+        return _stream(self.device)
+
+    def __exit__(self, *exc):
+        return self._guard.__exit__(*exc)
+
+
+_ST = object()  # placeholder for the stream argument of a library call
+
+
+def _call(name: str, tensors, *args):
+    """one library call on the device of `tensors` (all on one GPU) with that device current and its current stream"""
+    with _on(*tensors) as st:
+        rc = getattr(lib(), name)(*[st if a is _ST else a for a in args])
+    _check(rc, name)
+
+
+def debug_option(name: str, value=None):
+    """developer / test switches of the library (include/ganq_hip.h); value None resets to the default"""
+    if value is None:
+        _check(lib().ganq_debug_reset_option(name.encode()), "ganq_debug_reset_option")
+    else:
+        _check(lib().ganq_debug_set_option(name.encode(), int(value)), "ganq_debug_set_option")
+
+
+def debug_option_get(name: str) -> int:
+    v = ctypes.c_longlong(0)
+    _check(lib().ganq_debug_get_option(name.encode(), ctypes.byref(v)), "ganq_debug_get_option")
+    return v.value
 
 
 def _ptr(t):
@@ -143,16 +197,17 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def selftest():
-    _check(lib().ganq_hip_selftest(_stream()), "ganq_hip_selftest")
+def selftest(device=None):
+    """MFMA accumulation-order probe on `device` (default: the current device); cached per device by the library"""
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _check(lib().ganq_hip_selftest(_stream()), "ganq_hip_selftest")
 
 
 def debug_div_check(count: int, seed: int = 1):
     """(mismatches, (a, b)) of the reciprocal-based quotient vs IEEE division over `count` pseudo-random pairs"""
     bad = torch.zeros((), dtype=torch.int64, device="cuda")
     first = torch.zeros(2, dtype=torch.float32, device="cuda")
-    _check(lib().ganq_debug_div_check(int(count), int(seed), bad.data_ptr(), first.data_ptr(), _stream()),
-           "ganq_debug_div_check")
+    _call("ganq_debug_div_check", (bad, first), int(count), int(seed), bad.data_ptr(), first.data_ptr(), _ST)
     return int(bad), tuple(first.tolist())
 
 
@@ -162,8 +217,7 @@ def debug_wh_product(W, H):
     m, n = W.shape
     WH = torch.empty((m, n), dtype=torch.float64, device=W.device)
     Hf = torch.empty((n, n), dtype=torch.float64, device=W.device)
-    _check(lib().ganq_debug_wh_product(W.data_ptr(), H.data_ptr(), m, n, WH.data_ptr(), Hf.data_ptr(), _stream()),
-           "ganq_debug_wh_product")
+    _call("ganq_debug_wh_product", (W, H, WH, Hf), W.data_ptr(), H.data_ptr(), m, n, WH.data_ptr(), Hf.data_ptr(), _ST)
     return WH, Hf
 
 
@@ -179,8 +233,8 @@ def solve_s(W, L, T, want_err=False):
     Q = torch.empty((m, n), dtype=torch.uint8, device=W.device)
     Err = torch.empty((m, n), dtype=torch.float32, device=W.device) if want_err else None
     ws = _workspace(lib().ganq_solve_s_workspace_bytes(m, n, V), W.device)
-    _check(lib().ganq_solve_s(W.data_ptr(), L.data_ptr(), L.stride(0), T.data_ptr(), m, n, V, Q.data_ptr(), _ptr(Err),
-                              ws.data_ptr(), ws.numel(), _stream()), "ganq_solve_s")
+    _call("ganq_solve_s", (W, L, T, Q, Err, ws), W.data_ptr(), L.data_ptr(), L.stride(0), T.data_ptr(), m, n, V, Q.data_ptr(), _ptr(Err),
+                              ws.data_ptr(), ws.numel(), _ST)
     return (Q, Err) if want_err else Q
 
 
@@ -191,7 +245,7 @@ def matmul_f32(A, B):
         raise GanqHipError(f"shape mismatch A{tuple(A.shape)} B{tuple(B.shape)}")
     n = B.shape[1]
     C = torch.empty((m, n), dtype=torch.float32, device=A.device)
-    _check(lib().ganq_matmul_f32(A.data_ptr(), B.data_ptr(), m, k, n, C.data_ptr(), _stream()), "ganq_matmul_f32")
+    _call("ganq_matmul_f32", (A, B, C), A.data_ptr(), B.data_ptr(), m, k, n, C.data_ptr(), _ST)
     return C
 
 
@@ -206,8 +260,8 @@ def update_t(WH, H, Q, V, rcond=-1.0, want_ab=False):
     A = torch.empty((m, V, V), dtype=torch.float32, device=WH.device) if want_ab else None
     b = torch.empty((m, V), dtype=torch.float32, device=WH.device) if want_ab else None
     ws = _workspace(lib().ganq_update_t_workspace_bytes(m, n, V), WH.device)
-    _check(lib().ganq_update_t(WH.data_ptr(), H.data_ptr(), Q.data_ptr(), m, n, V, float(rcond), T.data_ptr(), _ptr(A),
-                               _ptr(b), ws.data_ptr(), ws.numel(), _stream()), "ganq_update_t")
+    _call("ganq_update_t", (WH, H, Q, T, A, b, ws), WH.data_ptr(), H.data_ptr(), Q.data_ptr(), m, n, V, float(rcond), T.data_ptr(), _ptr(A),
+                               _ptr(b), ws.data_ptr(), ws.numel(), _ST)
     return (T, A, b) if want_ab else T
 
 
@@ -218,8 +272,8 @@ def quad_loss(W, H, T, Q):
     m, n = W.shape
     out = torch.empty((), dtype=torch.float64, device=W.device)
     ws = _workspace(lib().ganq_quad_loss_workspace_bytes(m, n, T.shape[1]), W.device)
-    _check(lib().ganq_quad_loss(W.data_ptr(), H.data_ptr(), T.data_ptr(), Q.data_ptr(), m, n, T.shape[1],
-                                out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ganq_quad_loss")
+    _call("ganq_quad_loss", (W, H, T, Q, out, ws), W.data_ptr(), H.data_ptr(), T.data_ptr(), Q.data_ptr(), m, n, T.shape[1],
+                                out.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
     return out
 
 
@@ -231,8 +285,8 @@ def dequant_losses(W, T, Q, hinv_diag, want_losses=True):
     Wq = torch.empty((m, n), dtype=torch.float32, device=W.device)
     Lo = torch.empty((m, n), dtype=torch.float32, device=W.device) if want_losses else None
     hd = _dev_f32(hinv_diag, "hinv_diag") if want_losses else None
-    _check(lib().ganq_dequant_losses(W.data_ptr(), T.data_ptr(), Q.data_ptr(), _ptr(hd), m, n, T.shape[1],
-                                     Wq.data_ptr(), _ptr(Lo), _stream()), "ganq_dequant_losses")
+    _call("ganq_dequant_losses", (W, T, Q, hd, Wq, Lo), W.data_ptr(), T.data_ptr(), Q.data_ptr(), _ptr(hd), m, n, T.shape[1],
+                                     Wq.data_ptr(), _ptr(Lo), _ST)
     return Wq, Lo
 
 
@@ -254,11 +308,54 @@ def run_layer(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None):
     dists = torch.zeros((max(K, 1),), dtype=torch.float64, device=W.device)
     best_k = torch.full((), -1, dtype=torch.int32, device=W.device)
     ws = workspace if workspace is not None else run_layer_workspace(m, n, V, W.device)
-    _check(lib().ganq_run_layer(W.data_ptr(), H.data_ptr(), L.data_ptr(), L.stride(0), T0.data_ptr(), m, n, V, int(K),
+    _call("ganq_run_layer", (W, H, L, T0, T, Q, dists, best_k, ws), W.data_ptr(), H.data_ptr(), L.data_ptr(), L.stride(0), T0.data_ptr(), m, n, V, int(K),
                                 FLAG_ALIAS_Q if alias_q else 0, float(rcond), T.data_ptr(), Q.data_ptr(),
-                                dists.data_ptr(), best_k.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-           "ganq_run_layer")
+                                dists.data_ptr(), best_k.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
     return T, Q, dists[:K], best_k
+
+
+def run_layer_rows(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None, want_q_all=None):
+    """ganq_run_layer_rows: the fused loop on a slice of a layer's rows with the per-iteration records the owner of the
+    whole layer needs.  -> dict(T_all [K,m,V], loss_rows_all [K,m] fp64, Q_last [m,n] uint8 (indices of the last
+    iteration), Q_all [K,m,n] or None, dists [K] / best_k / T_best of the slice alone)."""
+    W, H, T0 = _dev_f32(W, "W"), _dev_f32(H, "H"), _dev_f32(T0, "T0")
+    if not (L.is_cuda and L.dtype == torch.float32 and L.stride(1) == 1):
+        L = _dev_f32(L, "L")
+    m, n = W.shape
+    V = T0.shape[1]
+    if H.shape != (n, n) or L.shape != (n, n) or T0.shape[0] != m:
+        raise GanqHipError(f"shape mismatch W{tuple(W.shape)} H{tuple(H.shape)} L{tuple(L.shape)} T0{tuple(T0.shape)}")
+    if want_q_all is None:
+        want_q_all = not alias_q
+    K = int(K)
+    dev = W.device
+    T = torch.empty((m, V), dtype=torch.float32, device=dev)
+    Q = torch.empty((m, n), dtype=torch.uint8, device=dev)
+    dists = torch.zeros((max(K, 1),), dtype=torch.float64, device=dev)
+    best_k = torch.full((), -1, dtype=torch.int32, device=dev)
+    T_all = torch.empty((K, m, V), dtype=torch.float32, device=dev)
+    loss_all = torch.empty((K, m), dtype=torch.float64, device=dev)
+    Q_all = torch.empty((K, m, n), dtype=torch.uint8, device=dev) if want_q_all else None
+    ws = workspace if workspace is not None else run_layer_workspace(m, n, V, dev)
+    # always run the aliasing variant inside the slice: Q then holds the LAST iteration's indices, which is what the
+    # reference's torch branch returns; the per-iteration indices (if wanted) come back in Q_all
+    _call("ganq_run_layer_rows", (W, H, L, T0, T, Q, dists, best_k, T_all, loss_all, Q_all, ws), W.data_ptr(), H.data_ptr(),
+          L.data_ptr(), L.stride(0), T0.data_ptr(), m, n, V, K, FLAG_ALIAS_Q, float(rcond), T.data_ptr(), Q.data_ptr(),
+          dists.data_ptr(), best_k.data_ptr(), T_all.data_ptr(), loss_all.data_ptr(), _ptr(Q_all), ws.data_ptr(), ws.numel(),
+          _ST)
+    return dict(T_all=T_all, loss_rows_all=loss_all, Q_last=Q, Q_all=Q_all, dists=dists[:K], best_k=best_k, T_best=T)
+
+
+def select_best(loss_rows_all):
+    """ganq_select_best: loss_rows_all [K,m] fp64 (all rows of the layer, row order) -> (dists [K] fp64, best_k int32 0-dim)"""
+    if loss_rows_all.dtype != torch.float64 or not loss_rows_all.is_cuda or loss_rows_all.dim() != 2:
+        raise GanqHipError("select_best: loss_rows_all must be a [K, m] float64 cuda tensor")
+    la = loss_rows_all.contiguous()
+    K, m = la.shape
+    dists = torch.zeros((max(K, 1),), dtype=torch.float64, device=la.device)
+    best_k = torch.full((), -1, dtype=torch.int32, device=la.device)
+    _call("ganq_select_best", (la, dists, best_k), la.data_ptr(), m, K, dists.data_ptr(), best_k.data_ptr(), _ST)
+    return dists[:K], best_k
 
 
 def profile_enable(on: bool = True, only: str = None):
@@ -306,8 +403,8 @@ def hessian_accum(H, X, nsamples_before: int, batch: int):
     rows, n = X.shape
     if H.shape != (n, n):
         raise GanqHipError(f"shape mismatch H{tuple(H.shape)} X{tuple(X.shape)}")
-    _check(lib().ganq_hessian_accum(H.data_ptr(), X.data_ptr(), code, rows, n, int(nsamples_before), int(batch),
-                                    _stream()), "ganq_hessian_accum")
+    _call("ganq_hessian_accum", (H, X), H.data_ptr(), X.data_ptr(), code, rows, n, int(nsamples_before), int(batch),
+                                    _ST)
     return H
 
 
@@ -321,8 +418,7 @@ def cholesky(H, check: bool = True):
     L = H.clone()
     info = torch.zeros((), dtype=torch.int32, device=H.device)
     ws = _workspace(lib().ganq_cholesky_workspace_bytes(n), H.device)
-    _check(lib().ganq_cholesky(L.data_ptr(), n, L.stride(0) if n else 0, info.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-           "ganq_cholesky")
+    _call("ganq_cholesky", (L, info, ws), L.data_ptr(), n, L.stride(0) if n else 0, info.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
     if not check:
         return L, info
     bad = int(info)
@@ -342,8 +438,7 @@ def kmeans_init(W, col_weight, V: int):
             raise GanqHipError("col_weight must have shape [n]")
     T0 = torch.empty((m, V), dtype=torch.float32, device=W.device)
     ws = _workspace(lib().ganq_kmeans_workspace_bytes(m, n, V), W.device)
-    _check(lib().ganq_kmeans_init(W.data_ptr(), _ptr(cw), m, n, V, T0.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-           "ganq_kmeans_init")
+    _call("ganq_kmeans_init", (W, cw, T0, ws), W.data_ptr(), _ptr(cw), m, n, V, T0.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
     return T0
 
 
@@ -354,7 +449,7 @@ def pack_indices(Q, bits: int):
     Q = Q.contiguous()
     m, n = Q.shape
     qw = torch.empty((n * bits // 32, m), dtype=torch.int32, device=Q.device)
-    _check(lib().ganq_pack_indices(Q.data_ptr(), m, n, bits, qw.data_ptr(), _stream()), "ganq_pack_indices")
+    _call("ganq_pack_indices", (Q, qw), Q.data_ptr(), m, n, bits, qw.data_ptr(), _ST)
     return qw
 
 
@@ -364,7 +459,7 @@ def unpack_indices(qweight, n: int, bits: int):
     qweight = qweight.contiguous()
     m = qweight.shape[1]
     Q = torch.empty((m, n), dtype=torch.uint8, device=qweight.device)
-    _check(lib().ganq_unpack_indices(qweight.data_ptr(), m, n, bits, Q.data_ptr(), _stream()), "ganq_unpack_indices")
+    _call("ganq_unpack_indices", (qweight, Q), qweight.data_ptr(), m, n, bits, Q.data_ptr(), _ST)
     return Q
 
 
@@ -373,8 +468,7 @@ def lut_dequant(qweight, lut, n: int, bits: int):
     qweight, lut = qweight.contiguous(), lut.contiguous()
     m = lut.shape[0]
     Wq = torch.empty((m, n), dtype=lut.dtype, device=lut.device)
-    _check(lib().ganq_lut_dequant(qweight.data_ptr(), lut.data_ptr(), code, m, n, bits, Wq.data_ptr(), _stream()),
-           "ganq_lut_dequant")
+    _call("ganq_lut_dequant", (qweight, lut, Wq), qweight.data_ptr(), lut.data_ptr(), code, m, n, bits, Wq.data_ptr(), _ST)
     return Wq
 
 
@@ -382,11 +476,11 @@ _LUT_WS = {}  # (device index, stream) -> zero-initialised workspace, kept acros
 
 
 def _lut_workspace(nbytes: int, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(device))
     ws = _LUT_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _check(lib().ganq_lut_linear_workspace_init(ws.data_ptr(), ws.numel(), _stream()), "ganq_lut_linear_workspace_init")
+        _call("ganq_lut_linear_workspace_init", (ws,), ws.data_ptr(), ws.numel(), _ST)
         _LUT_WS[key] = ws
     return ws
 
@@ -399,14 +493,14 @@ def outlier_split(W, ratio: float):
     cut = torch.empty((m, 2), dtype=torch.float32, device=W.device)
     counts = torch.empty((m,), dtype=torch.int32, device=W.device)
     rowptr = torch.empty((m + 1,), dtype=torch.int32, device=W.device)
-    _check(lib().ganq_outlier_cutoffs(W.data_ptr(), m, n, float(ratio), cut.data_ptr(), counts.data_ptr(), rowptr.data_ptr(),
-                                      _stream()), "ganq_outlier_cutoffs")
+    _call("ganq_outlier_cutoffs", (W, cut, counts, rowptr), W.data_ptr(), m, n, float(ratio), cut.data_ptr(), counts.data_ptr(), rowptr.data_ptr(),
+                                      _ST)
     nnz = int(rowptr[m])  # the one host read: sizes of the CSR arrays
     cols = torch.empty((nnz,), dtype=torch.int32, device=W.device)
     vals = torch.empty((nnz,), dtype=torch.float32, device=W.device)
     if nnz:
-        _check(lib().ganq_outlier_extract(W.data_ptr(), m, n, cut.data_ptr(), rowptr.data_ptr(), cols.data_ptr(), vals.data_ptr(),
-                                          _stream()), "ganq_outlier_extract")
+        _call("ganq_outlier_extract", (W, cut, rowptr, cols, vals), W.data_ptr(), m, n, cut.data_ptr(), rowptr.data_ptr(), cols.data_ptr(), vals.data_ptr(),
+                                          _ST)
     return rowptr, cols, vals, cut
 
 
@@ -420,8 +514,8 @@ def outlier_matmul(x, rowptr, cols, vals, m: int):
     x = x.contiguous()
     M, n = x.shape
     out = torch.empty((M, m), dtype=torch.float32, device=x.device)
-    _check(lib().ganq_outlier_matmul(x.data_ptr(), code, M, m, n, rowptr.data_ptr(), _ptr(cols) if cols.numel() else None,
-                                     _ptr(vals) if vals.numel() else None, out.data_ptr(), _stream()), "ganq_outlier_matmul")
+    _call("ganq_outlier_matmul", (x, rowptr, cols, vals, out), x.data_ptr(), code, M, m, n, rowptr.data_ptr(), _ptr(cols) if cols.numel() else None,
+                                     _ptr(vals) if vals.numel() else None, out.data_ptr(), _ST)
     return out
 
 
@@ -437,10 +531,10 @@ def lut_linear_outliers(x, qweight, lut, bias, bits: int, rowptr, cols, vals):
     m = lut.shape[0]
     y = torch.empty((M, m), dtype=x.dtype, device=x.device)
     ws = _lut_workspace(lib().ganq_lut_linear_outliers_workspace_bytes(M, m, n, bits), x.device)
-    _check(lib().ganq_lut_linear_fwd_outliers(x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), rowptr.data_ptr(),
+    _call("ganq_lut_linear_fwd_outliers", (x, qweight, lut, bias, rowptr, cols, vals, y, ws), x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), rowptr.data_ptr(),
                                               cols.data_ptr() if cols.numel() else None,
                                               vals.data_ptr() if vals.numel() else None, code, M, m, n, bits, y.data_ptr(),
-                                              ws.data_ptr(), ws.numel(), _stream()), "ganq_lut_linear_fwd_outliers")
+                                              ws.data_ptr(), ws.numel(), _ST)
     return y
 
 
@@ -458,10 +552,9 @@ def lut_linear(x, qweight, lut, bias, bits: int, addend=None):
     if addend is not None:
         if addend.dtype != torch.float32 or tuple(addend.shape) != (M, m) or not addend.is_contiguous():
             raise GanqHipError("lut_linear: addend must be a contiguous fp32 [M, out_features] tensor")
-        _check(lib().ganq_lut_linear_fwd_add(x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), addend.data_ptr(), code,
-                                             M, m, n, bits, y.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-               "ganq_lut_linear_fwd_add")
+        _call("ganq_lut_linear_fwd_add", (x, qweight, lut, bias, addend, y, ws), x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), addend.data_ptr(), code,
+                                             M, m, n, bits, y.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
         return y
-    _check(lib().ganq_lut_linear_fwd(x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), code, M, m, n, bits,
-                                     y.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ganq_lut_linear_fwd")
+    _call("ganq_lut_linear_fwd", (x, qweight, lut, bias, y, ws), x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), code, M, m, n, bits,
+                                     y.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
     return y

@@ -14,6 +14,8 @@
 // reads info once at the end.
 #include <cstdlib>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace ganq {
@@ -308,9 +310,11 @@ Lookahead* lookahead_for(hipStream_t main) {
     };
     static Slot slots[32];
     static int used = 0;
-    static const bool off = [] { const char* e = getenv("GANQ_CHOL_LOOKAHEAD"); return e && e[0] == '0'; }();
+    static std::mutex mu;
+    const bool off = opt_get(OPT_CHOL_LOOKAHEAD) == 0;
     int dev = 0;
     if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     for (int i = 0; i < used; ++i)
         if (slots[i].dev == dev && slots[i].main == main) return &slots[i].la;
     if (used == 32) return nullptr;  // more caller streams than slots: plain single-stream factorisation
@@ -339,15 +343,11 @@ extern "C" int ganq_cholesky(float* A, int64_t n, int64_t lda, int32_t* info_out
     const size_t smem = 2 * (size_t)CB * CP * sizeof(float);
     const size_t smem_diag = ((size_t)CB * CP + 4 * 32 * XP) * sizeof(float);
     const size_t smem_panel = (2 * (size_t)CB * CP + 4 * 32 * XP) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_diag));
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_panel));
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_update_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
+    {
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(chol_diag_kernel), smem_diag);
+        if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(chol_panel_kernel), smem_panel);
+        if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(chol_update_kernel), smem);
+        if (rc) return rc;
     }
     ProfScope prof(KID_CHOLESKY, stream);
     GANQ_HIP_CHECK(hipMemsetAsync(info_out, 0, sizeof(int32_t), stream));

@@ -41,8 +41,33 @@ struct Carver {
 };
 
 // 1 if v_mfma_f32_16x16x4_f32 accumulates k = 0,1,2,3 in that order (fma(a3,b3,fma(a2,b2,fma(a1,b1,fma(a0,b0,c))))),
-// 0 if k = 3,2,1,0; negative until ganq_hip_selftest has run / on failure.
+// 0 if k = 3,2,1,0; negative until ganq_hip_selftest has run on the current device / on failure.
 int mfma_k_ascending();
+
+// developer / test switches (runtime.hip): read from the environment once at library load, changed by tests through
+// ganq_debug_set_option(); the compute path reads an atomic
+enum Opt : int {
+    OPT_T_FULL = 0,
+    OPT_T_INCR_THR,
+    OPT_T_JACOBI,
+    OPT_SOLVE_ALL_ROWS,
+    OPT_MUPDATE_LDS,
+    OPT_WH_F64,
+    OPT_KMEANS_WCAP,
+    OPT_CHOL_LOOKAHEAD,
+    OPT_ACCUM_DEBUG,
+    OPT_LUT_INWG,
+    OPT_LUT_WGS,
+    OPT_LUT_KS,
+    OPT_H_EXT,
+    OPT_SOLVE_VARIANT,
+    OPT_COUNT
+};
+long long opt_get(int id);
+
+// raise a kernel's dynamic-LDS limit above the 64 KB default on the CURRENT device if that has not been done yet
+// (recorded per (device, kernel) under a mutex)
+int ensure_dynamic_lds(const void* func, size_t bytes);
 
 // ---- optional per-kernel timing (profile.hip) ----
 enum KernelId : int {

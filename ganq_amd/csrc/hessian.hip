@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
     // fast path (uniform per workgroup): full, 16-byte aligned tile columns -> unconditional loads (a token row past
     // the end is clamped and zeroed afterwards), so that the compiler can count the loads in flight instead of
     // draining them at every slab
-    const bool fast = (u0 + HT <= n) && (v0 + HT <= n) && ((n & 7) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    // (rows == 0, an empty batch, only decays H: the fast path's clamp to row rows-1 would read out of bounds)
+    const bool fast = rows > 0 && (u0 + HT <= n) && (v0 + HT <= n) && ((n & 7) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     auto gload = [&](auto fast_tag, int t0, uint4 (&ra)[HL], uint4 (&rb)[HL]) {
         constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll

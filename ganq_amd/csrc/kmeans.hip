@@ -750,8 +750,7 @@ static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
     p.qcap = km_queue_cap(n);
     const size_t lds_bytes = align_up(4 * (size_t)(n + 1) * sizeof(double) + (size_t)n * sizeof(uint16_t), 16) + km_queue_bytes(p.qcap);
     p.lds = lds_bytes <= KM_LDS_BUDGET;
-    const char* force = getenv("GANQ_KMEANS_WCAP");  // testing: force the windowed kernel with a small window
-    const int forced = force ? atoi(force) : 0;
+    const int forced = (int)opt_get(OPT_KMEANS_WCAP);  // testing: force the windowed kernel with a small window
     if (forced > 0) p.lds = false;
     if (p.lds) {
         p.smem = lds_bytes;
@@ -799,20 +798,16 @@ extern "C" int ganq_kmeans_init(const float* W, const double* col_weight, int64_
     if (!workspace || workspace_bytes < need)
         return fail(-4, "ganq_kmeans_init: workspace %zu B < required %zu B", workspace_bytes, need);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static size_t attr_smem[2] = {0, 0};
-    if (p.smem > attr_smem[p.lds]) {
+    {
+        int rc;
         if (p.lds) {
-            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_lds_kernel<4>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
-            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_lds_kernel<8>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
+            rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kmeans_lds_kernel<4>), p.smem);
+            if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kmeans_lds_kernel<8>), p.smem);
         } else {
-            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_win_kernel<4>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
-            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_win_kernel<8>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem));
+            rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kmeans_win_kernel<4>), p.smem);
+            if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kmeans_win_kernel<8>), p.smem);
         }
-        attr_smem[p.lds] = p.smem;
+        if (rc) return rc;
     }
     ProfScope prof(KID_KMEANS, stream);
     if (p.lds && p.per_cu >= 2)

@@ -343,6 +343,11 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict_
     Q[i] = (uint8_t)(v & ((1u << bits) - 1u));
 }
 
+// The ticket counters occupy a FIXED region at the head of the workspace (one int per block of output features, up to
+// 16384 blocks), the partial tiles start behind it: one workspace serves layers of any shape in turn, and the floats
+// a smaller layer left in the partial-tile region can never be read as counters by a larger one.
+constexpr size_t LUT_COUNTER_BYTES = 64 * 1024;
+
 struct LutPlan {
     bool inwg;  // the waves of a workgroup split in_features among themselves (no exchange through memory)
     int ob, KS, kb_per_wg;
@@ -353,29 +358,29 @@ static LutPlan lut_plan(int64_t M, int64_t m, int64_t n, int bits) {
     // (the partial tiles are KS*M*m floats and the last workgroup of a feature block sums KS of them)
     LutPlan p;
     const int nkb = (int)(n >> 5);
-    static const int inwg_env = getenv("GANQ_LUT_INWG") ? atoi(getenv("GANQ_LUT_INWG")) : -1;
+    const int inwg_env = (int)opt_get(OPT_LUT_INWG);
     // enough 32-feature workgroups to occupy the chip, and a reduction buffer that fits LDS (two row tiles)
     p.inwg = inwg_env >= 0 ? (inwg_env != 0 && M <= 32) : (M <= 32 && (m + 31) / 32 >= 96);
     if (p.inwg) {
         p.ob = (int)((m + 31) / 32);
         p.KS = 1;
         p.kb_per_wg = (nkb + LWK - 1) / LWK;  // per wave
-        p.counter_bytes = align_up((size_t)p.ob * sizeof(int), 256);
+        p.counter_bytes = LUT_COUNTER_BYTES;
         p.bytes = p.counter_bytes;  // kept non-zero so that callers can reuse one workspace for every shape
         return p;
     }
     p.ob = (int)((m + LUT_FB - 1) / LUT_FB);
-    static const int target_env = getenv("GANQ_LUT_WGS") ? atoi(getenv("GANQ_LUT_WGS")) : 0;
+    const int target_env = (int)opt_get(OPT_LUT_WGS);
     // measured on MI355X (tools/lut_trace.sh): ~512 workgroups, and at most 8 / 4 / 2 splits for M <= 16 / 32 / 64 --
     // the exchange of partial tiles goes through memory (device-scope accesses) and its cost grows with KS * M
-    static const int cap_env = getenv("GANQ_LUT_KS") ? atoi(getenv("GANQ_LUT_KS")) : 0;
+    const int cap_env = (int)opt_get(OPT_LUT_KS);
     const int target = target_env > 0 ? target_env : 512;
     const int cap = cap_env > 0 ? cap_env : (M <= 16 ? 8 : (M <= 32 ? 4 : 2));
     int ks = std::max(1, std::min(std::min(nkb / 2, cap), (target + p.ob - 1) / p.ob));
     (void)bits;
     p.kb_per_wg = (nkb + ks - 1) / ks;
     p.KS = (nkb + p.kb_per_wg - 1) / p.kb_per_wg;
-    p.counter_bytes = align_up((size_t)p.ob * sizeof(int), 256);
+    p.counter_bytes = LUT_COUNTER_BYTES;
     p.bytes = p.counter_bytes + (p.KS > 1 ? align_up((size_t)p.KS * (size_t)M * (size_t)m * sizeof(float), 256) : 0);
     return p;
 }
@@ -458,6 +463,9 @@ static int lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut
     if ((reinterpret_cast<uintptr_t>(lut) & 3) != 0) return fail(-2, "ganq_lut_linear_fwd: lut must be 4-byte aligned");
     if (!x || !qweight || !lut || !y) return fail(-3, "ganq_lut_linear_fwd: null pointer");
     const LutPlan p = lut_plan(M, m, n, bits);
+    if ((size_t)p.ob * sizeof(int) > LUT_COUNTER_BYTES)
+        return fail(-2, "ganq_lut_linear_fwd: out_features=%lld needs more than %zu ticket counters", (long long)m,
+                    LUT_COUNTER_BYTES / sizeof(int));
     if (!workspace || workspace_bytes < p.bytes)
         return fail(-4, "ganq_lut_linear_fwd: workspace %zu B < required %zu B", workspace_bytes, p.bytes);
     hipStream_t stream = static_cast<hipStream_t>(stream_);

@@ -193,11 +193,9 @@ extern "C" int ganq_outlier_cutoffs(const float* W, int64_t m, int64_t n, double
     upper = std::min(std::max(upper, 0), (int)n - 1);
     lower = std::min(std::max(lower, 0), (int)n - 1);
     const size_t smem = ((size_t)n + 256 + 2) * sizeof(uint32_t);
-    static size_t attr = 0;
-    if (smem > 64 * 1024 && smem > attr) {
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(outlier_cutoff_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = smem;
+    {
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(outlier_cutoff_kernel), smem);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(outlier_cutoff_kernel, dim3((unsigned)m), dim3(256), smem, stream, W, (int)m, (int)n, lower, upper, cut,
                        counts);

@@ -110,9 +110,12 @@ extern "C" size_t ganq_run_layer_workspace_bytes(int64_t m, int64_t n, int V) {
     return run_layout(m, n, V).total;
 }
 
-extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, int64_t ldl, const float* T0, int64_t m,
-                              int64_t n, int V, int K, uint32_t flags, double rcond, float* T_best, uint8_t* Q_out,
-                              double* dists, int32_t* best_k, void* workspace, size_t workspace_bytes, void* stream_) {
+// shared body of ganq_run_layer / ganq_run_layer_rows.  T_all [K,m,V], loss_rows_all [K,m], Q_all [K,m,n]: optional
+// per-iteration records (device; null = not wanted)
+static int run_layer_impl(const float* W, const float* H, const float* L, int64_t ldl, const float* T0, int64_t m,
+                          int64_t n, int V, int K, uint32_t flags, double rcond, float* T_best, uint8_t* Q_out,
+                          double* dists, int32_t* best_k, float* T_all, double* loss_rows_all, uint8_t* Q_all,
+                          void* workspace, size_t workspace_bytes, void* stream_) {
     if (m < 0 || n < 0 || K < 0) return fail(-1, "ganq_run_layer: negative shape / K");
     if (m == 0 || n == 0 || K == 0) return 0;
     if (V < 2 || V > 16) return fail(-2, "ganq_run_layer: V=%d not supported (bits 2..4 are implemented)", V);
@@ -160,6 +163,14 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
             if (rc) return rc;
         }
         std::swap(Tc, Tn);
+        // per-iteration records for a caller that takes the best-of-K decision itself (row-sharded layers, tests)
+        if (T_all)
+            GANQ_HIP_CHECK(hipMemcpyAsync(T_all + (size_t)k * m * V, Tc, (size_t)m * V * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        if (loss_rows_all)
+            GANQ_HIP_CHECK(hipMemcpyAsync(loss_rows_all + (size_t)k * m, t_loss_rows(lo.t, ws + lo.off_upd), (size_t)m * sizeof(double),
+                                          hipMemcpyDeviceToDevice, stream));
+        if (Q_all)
+            GANQ_HIP_CHECK(hipMemcpyAsync(Q_all + (size_t)k * m * n, Qwork, (size_t)m * n, hipMemcpyDeviceToDevice, stream));
         {
             const int64_t words = m * V;  // fp32 codebook
             const int blocks = (int)std::min<int64_t>(64, std::max<int64_t>(1, (words + 255) / 256));
@@ -178,6 +189,67 @@ extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, in
         }
     }
     hipLaunchKernelGGL(copy_if_none_kernel, dim3(64), dim3(256), 0, stream, best_k, Tc, T_best, (int64_t)m * V);
+    GANQ_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ganq_run_layer(const float* W, const float* H, const float* L, int64_t ldl, const float* T0, int64_t m,
+                              int64_t n, int V, int K, uint32_t flags, double rcond, float* T_best, uint8_t* Q_out,
+                              double* dists, int32_t* best_k, void* workspace, size_t workspace_bytes, void* stream_) {
+    return run_layer_impl(W, H, L, ldl, T0, m, n, V, K, flags, rcond, T_best, Q_out, dists, best_k, nullptr, nullptr, nullptr,
+                          workspace, workspace_bytes, stream_);
+}
+
+// The same fused loop on a SLICE of the rows of a layer (rows are independent in every stage; only the best-of-K decision
+// is global), with the per-iteration records the owner of the whole layer needs to take that decision:
+// T_all [K,m,V] codebooks, loss_rows_all [K,m] per-row losses, Q_all [K,m,n] indices (each optional).  dists / best_k /
+// T_best / Q_out describe the slice alone.  See ganq_select_best for the global decision.
+extern "C" int ganq_run_layer_rows(const float* W, const float* H, const float* L, int64_t ldl, const float* T0, int64_t m,
+                                   int64_t n, int V, int K, uint32_t flags, double rcond, float* T_best, uint8_t* Q_out,
+                                   double* dists, int32_t* best_k, float* T_all, double* loss_rows_all, uint8_t* Q_all,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+    return run_layer_impl(W, H, L, ldl, T0, m, n, V, K, flags, rcond, T_best, Q_out, dists, best_k, T_all, loss_rows_all, Q_all,
+                          workspace, workspace_bytes, stream_);
+}
+
+namespace ganq {
+// dist_k = sum of the K x m per-row losses in the loop's own order (256 strided partial sums, binary tree), best_k =
+// first k with the smallest dist (strict <, NaN never wins): bit-identical to the decisions of select_copy_kernel
+__global__ __launch_bounds__(256) void select_best_kernel(const double* __restrict__ loss_rows_all, int m, int K,
+                                                          double* __restrict__ dists, int32_t* __restrict__ best_k) {
+    __shared__ double sh[256];
+    double best = INFINITY;
+    int bk = -1;
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < m; i += 256) s += loss_rows_all[(int64_t)k * m + i];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+            __syncthreads();
+        }
+        const double d = sh[0];
+        __syncthreads();
+        if (threadIdx.x == 0) dists[k] = d;
+        if (d < best) {
+            best = d;
+            bk = k;
+        }
+    }
+    if (threadIdx.x == 0) *best_k = bk;
+}
+}  // namespace ganq
+
+// ganq.py:621-626 over the gathered per-row losses of all row slices of a layer: loss_rows_all [K, m] (m = all rows, in
+// row order) -> dists [K] fp64, best_k int32 (device).  Same summation order as the single-call loop, so a row-sharded
+// layer takes bit-for-bit the decision the unsharded one takes.
+extern "C" int ganq_select_best(const double* loss_rows_all, int64_t m, int K, double* dists, int32_t* best_k, void* stream_) {
+    if (m < 0 || K < 0) return fail(-1, "ganq_select_best: negative shape");
+    if (!dists || !best_k || (!loss_rows_all && m > 0 && K > 0)) return fail(-3, "ganq_select_best: null pointer");
+    if (m > INT32_MAX / 2) return fail(-1, "ganq_select_best: m too large");
+    hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), loss_rows_all, (int)m, K, dists,
+                       best_k);
     GANQ_LAUNCH_CHECK();
     return 0;
 }

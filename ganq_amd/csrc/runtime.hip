@@ -1,0 +1,109 @@
+// Process-wide runtime state of libganq_hip.so that is NOT on any hot path:
+//   * developer / test switches ("options"): read from the environment ONCE, when the library is loaded, and kept in
+//     atomics; tests change them through ganq_debug_set_option() instead of the environment.  The compute entry
+//     points read an atomic, never getenv();
+//   * the per-(device, kernel) record of the dynamic-LDS limit already raised with hipFuncSetAttribute -- the
+//     attribute is per device, and the C-ABI promises re-entrancy per (device, stream), so the record is keyed by
+//     hipGetDevice() and guarded by a mutex.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "common.h"
+
+namespace ganq {
+
+namespace {
+
+struct OptDesc {
+    const char* name;  // option name == environment variable read at load
+    long long def;
+};
+
+// order == enum Opt in common.h
+const OptDesc kOpts[OPT_COUNT] = {
+    {"GANQ_T_FULL", 0},            // 1: stateless full bucket accumulation in every iteration
+    {"GANQ_T_INCR_THR", -1},       // >= 0: changed-index count above which the device falls back to the full accumulation
+    {"GANQ_T_JACOBI", 0},          // 1: every row by the Jacobi eigen-solve (no Cholesky fast path)
+    {"GANQ_SOLVE_ALL_ROWS", 0},    // 1: the S-solve never skips converged rows
+    {"GANQ_MUPDATE_LDS", 0},       // 1: LDS-histogram version of the incremental update
+    {"GANQ_WH_F64", 0},            // 1: W @ H_fixed by the fp64 GEMM instead of the split-fp16 product
+    {"GANQ_KMEANS_WCAP", 0},       // > 0: force the windowed k-means kernel with this window
+    {"GANQ_CHOL_LOOKAHEAD", 1},    // 0: no second stream in the Cholesky trailing update
+    {"GANQ_ACCUM_DEBUG", 0},       // 1: print cycle stamps of onehot_accum_kernel (synchronises)
+    {"GANQ_LUT_INWG", -1},         // LUT forward: force (1) / forbid (0) the in-workgroup reduction
+    {"GANQ_LUT_WGS", 0},           // LUT forward: workgroup target
+    {"GANQ_LUT_KS", 0},            // LUT forward: cap of the split-K factor
+    {"GANQ_H_EXT", -1},            // fixed-point H: 1 force / 0 forbid the 16-bit extension word (-1: decided on the device)
+    {"GANQ_SOLVE_VARIANT", 0},     // S-solve scheduling variant (developer A/B)
+};
+
+std::atomic<long long> g_opt[OPT_COUNT];
+
+struct OptInit {
+    OptInit() {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            long long v = kOpts[i].def;
+            const char* e = getenv(kOpts[i].name);
+            if (e && *e) v = atoll(e);
+            g_opt[i].store(v, std::memory_order_relaxed);
+        }
+    }
+} g_opt_init;  // runs when the shared object is loaded
+
+std::mutex g_attr_mu;
+std::map<std::pair<int, const void*>, size_t> g_attr;  // (device, kernel) -> dynamic LDS bytes already allowed
+
+}  // namespace
+
+long long opt_get(int id) { return g_opt[id].load(std::memory_order_relaxed); }
+
+int ensure_dynamic_lds(const void* func, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;  // the default limit
+    int dev = 0;
+    GANQ_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_attr_mu);
+    size_t& have = g_attr[std::make_pair(dev, func)];
+    if (bytes > have) {
+        GANQ_HIP_CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return 0;
+}
+
+}  // namespace ganq
+
+using namespace ganq;
+
+extern "C" int ganq_debug_set_option(const char* name, long long value) {
+    if (!name) return fail(-3, "ganq_debug_set_option: null name");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (std::strcmp(name, kOpts[i].name) == 0) {
+            g_opt[i].store(value, std::memory_order_relaxed);
+            return 0;
+        }
+    return fail(-1, "ganq_debug_set_option: unknown option %s", name);
+}
+
+extern "C" int ganq_debug_get_option(const char* name, long long* value) {
+    if (!name || !value) return fail(-3, "ganq_debug_get_option: null pointer");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (std::strcmp(name, kOpts[i].name) == 0) {
+            *value = g_opt[i].load(std::memory_order_relaxed);
+            return 0;
+        }
+    return fail(-1, "ganq_debug_get_option: unknown option %s", name);
+}
+
+extern "C" int ganq_debug_reset_option(const char* name) {
+    if (!name) return fail(-3, "ganq_debug_reset_option: null name");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (std::strcmp(name, kOpts[i].name) == 0) {
+            g_opt[i].store(kOpts[i].def, std::memory_order_relaxed);
+            return 0;
+        }
+    return fail(-1, "ganq_debug_reset_option: unknown option %s", name);
+}

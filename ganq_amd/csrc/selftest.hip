@@ -23,9 +23,25 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-static int g_k_ascending = -1;
+// per device (the probe runs once on each device the library is used on; all entries start at "not run")
+constexpr int MAX_DEVICES = 64;
+static int g_k_ascending[MAX_DEVICES];
+static bool g_probe_init = [] {
+    for (int& v : g_k_ascending) v = -1;
+    return true;
+}();
 static std::mutex g_probe_mutex;
-int mfma_k_ascending() { return g_k_ascending; }
+static int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return -1;
+    return dev;
+}
+int mfma_k_ascending() {
+    const int dev = current_device_slot();
+    if (dev < 0) return -1;
+    std::lock_guard<std::mutex> lock(g_probe_mutex);
+    return g_k_ascending[dev];
+}
 
 __global__ void probe_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                   const float* __restrict__ C, float* __restrict__ D) {
@@ -89,8 +105,10 @@ extern "C" int ganq_hip_version(void) { return GANQ_HIP_ABI_VERSION; }
 extern "C" const char* ganq_hip_last_error(void) { return error_buffer(); }
 
 extern "C" int ganq_hip_selftest(void* stream_) {
+    const int dev = current_device_slot();
+    if (dev < 0) return fail(-100, "ganq_hip_selftest: no current HIP device (or device index >= %d)", MAX_DEVICES);
     std::lock_guard<std::mutex> lock(g_probe_mutex);
-    if (g_k_ascending >= 0) return 0;
+    if (g_k_ascending[dev] >= 0) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float hA[64], hB[64], hC[256], hD[256];
     uint32_t s = 12345u;
@@ -128,9 +146,9 @@ extern "C" int ganq_hip_selftest(void* stream_) {
         }
     if (differ < 16) return fail(-101, "mfma probe data not order-sensitive (%d)", differ);
     if (asc == 256 && desc < 256) {
-        g_k_ascending = 1;
+        g_k_ascending[dev] = 1;
     } else if (desc == 256 && asc < 256) {
-        g_k_ascending = 0;
+        g_k_ascending[dev] = 0;
     } else {
         return fail(-102, "v_mfma_f32_16x16x4_f32 is not an ordered fmaf chain on this device (asc %d desc %d of 256)",
                     asc, desc);

@@ -427,13 +427,10 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
     // the Err blocks of the top SOLVE_LDS_PANELS panels (the ones every later panel re-reads) stay in LDS
     const int pbase = std::max(0, lo.nb - SOLVE_LDS_PANELS);
     const size_t smem = (size_t)(lo.nb - pbase) * 4096;
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_s_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_smem = smem;
+    {
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(solve_s_kernel<true>), smem);
+        if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(solve_s_kernel<false>), smem);
+        if (rc) return rc;
     }
     ProfScope prof(KID_SOLVE_S, stream);
     if (mfma_k_ascending()) {

@@ -12,6 +12,9 @@ struct TLayout {
     // split-fp16 W @ H_fixed (wh_gemm.hip): packed pieces of W and H, row exponents, Wlo flags
     size_t off_wp, off_hp, off_rexp, off_wlo;
     size_t off_active;  // rows that changed in the last iteration (S-solve work list)
+    // extension word of the fixed-point H (planes 4..5 live behind planes 0..3): its diagonal, its partial / kept bucket
+    // sums, its int16 copy; per-feature exponents of the symmetric scaling used by the W @ H product
+    size_t off_hdiag_j, off_mpart_lo, off_mstate_lo, off_jint, off_dexp, off_hdiag64;
 };
 
 TLayout t_layout(int64_t m, int64_t n, bool with_f64);

@@ -6,8 +6,13 @@
 //
 // A_i[a][b] = sum_{u,v} [Q_iu == a][Q_iv == b] H[u,v] is a bucket sum of ALL of H per row: m*n^2 additions.
 // It runs on the integer matrix cores, exactly:
-//   * once per layer H is converted to 31-bit fixed point (scale = max|H| / 2^30) and split into 4 balanced
-//     base-256 digits, stored as 4 int8 planes Hq[p][v][u] (t_prepare);
+//   * once per layer H is converted to fixed point, H ~= scale * (I + J / 65536) with scale = max|H| / 2^30: I is a
+//     31-bit integer split into 4 balanced base-256 digits (int8 planes 0..3 of Hq[p][v][u]); J is a 16-bit
+//     EXTENSION word (2 more digits, planes 4..5) that exists only when the dynamic range of H needs it -- decided on
+//     the device, max|H| > 16 mean(diag H): with massive-activation features (H_ii 10^4..10^6 x the typical one) a
+//     31-bit word leaves the typical entry 10-17 significant bits, against the 24 of the fp32 entries the reference
+//     sums (ganq.py:589-591); 47 bits keep every entry of a matrix spanning 2^23 to full fp32 precision.  The bucket
+//     sums of I and J are kept as two exact int64 words and meet in fp64 in the per-row solve (t_prepare);
 //   * per iteration the indices become bit masks bits[row][u/64][code] (one ballot per code);
 //   * v_mfma_i32_16x16x64_i8 multiplies the one-hot matrix [16 codes x 64 u] (expanded from 16 mask bits per lane
 //     with one integer multiply per 4 bytes) with a digit tile [64 u x 16 v]: int32 accumulators hold
@@ -44,17 +49,20 @@ constexpr int KS64 = UT / 64;
 constexpr int UC16 = UT / 16;   // 16-byte pieces per tile row
 constexpr int NP = 8;           // chunk c belongs to part c % NP; every part writes one partial A
 constexpr int BROW = UT + 16;   // LDS row pitch of a digit tile in bytes (pad against bank conflicts)
-constexpr int BTILE = 4 * VCH * BROW;
+constexpr int btile_bytes(int npl) { return npl * VCH * BROW; }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct TPrep {              // device-side header written by t_prepare
-    double scale;           // H ~= scale * integer
+    double scale;           // H ~= scale * (I + J / 65536)
     unsigned int absmax_bits;
-    unsigned int pad;
+    int ext;                // 1: the 16-bit extension word J is in use (planes 4..5, Jint, the *_lo bucket sums)
 };
+constexpr double EXT_UNIT = 1.0 / 65536.0;
+// two balanced base-256 digits hold J in [-32896, 32639]: the int16 copy stores J + JBIAS, which is exactly [-32768, 32767]
+constexpr int JBIAS = 128;
 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ H, int64_t total, TPrep* __restrict__ prep) {
@@ -75,32 +83,66 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ H
     if (threadIdx.x == 0) atomicMax(&prep->absmax_bits, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
 }
 
-__global__ void prep_scale_kernel(TPrep* prep) {
-    const float mx = __builtin_bit_cast(float, prep->absmax_bits);
-    prep->scale = (mx > 0.0f && mx < __builtin_inff()) ? (double)mx / 1073741824.0 : 0.0;
+// scale = max|H| / 2^30; the extension word is switched on when the matrix has more dynamic range than one 31-bit
+// word serves: a bucket sum A[a][a] is about (n / V) mean(diag H), its rounding error about (n / V) 0.29 scale, so with
+// max|H| <= 16 mean(diag H) one word keeps A to 4e-9 relative -- beyond that the second word takes over.
+// ext_mode: -1 decide here, 0 never, 1 always (developer switch GANQ_H_EXT).
+__global__ __launch_bounds__(256) void prep_scale_kernel(const float* __restrict__ H, int n, TPrep* prep, int ext_mode) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int u = threadIdx.x; u < n; u += 256) s += (double)H[(int64_t)u * n + u];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = __builtin_bit_cast(float, prep->absmax_bits);
+        const bool ok = mx > 0.0f && mx < __builtin_inff();
+        prep->scale = ok ? (double)mx / 1073741824.0 : 0.0;
+        const double mean_diag = sh[0] / (double)n;
+        const bool wide = ok && !((double)mx <= 16.0 * mean_diag);  // also for a non-positive / NaN mean
+        prep->ext = ext_mode < 0 ? (wide ? 1 : 0) : (ext_mode ? 1 : 0);
+    }
 }
 
-// planes[p][v][u] (row pitch nq, zero padded), hdiag_int[u], optionally H64[v][u] = scale * integer
+// planes[p][v][u] (row pitch nq, zero padded; p = 0..3 digits of I, p = 4..5 digits of J), hdiag_int[u] / hdiag_j[u],
+// optionally H64[v][u] = scale * (I + J / 65536), Hint = I (int32), Jint = J (int16)
 __global__ __launch_bounds__(256) void hquant_kernel(const float* __restrict__ H, int n, int nq, const TPrep* __restrict__ prep,
                                                     int8_t* __restrict__ planes, int* __restrict__ hdiag_int,
-                                                    double* __restrict__ H64, int* __restrict__ Hint) {
+                                                    int* __restrict__ hdiag_j, double* __restrict__ H64,
+                                                    int* __restrict__ Hint, short* __restrict__ Jint) {
     const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;  // 4 consecutive u of one row v
     const int64_t per_row = nq;
     if (i4 >= (int64_t)n * per_row) return;
     const int v = (int)(i4 / per_row), u0 = (int)(i4 % per_row);
     const double scale = prep->scale;
+    const bool ext = prep->ext != 0;
     const double inv = scale > 0.0 ? 1.0 / scale : 0.0;
-    uint32_t pk[4] = {0, 0, 0, 0};
+    uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int u = u0 + k;
-        int xi = 0;
+        int xi = 0, xj = 0;
         if (u < n) {
-            const double x = (double)H[(int64_t)v * n + u] * inv;
-            xi = (int)__builtin_rint(fmin(fmax(x, -1073741824.0), 1073741824.0));
-            if (H64) H64[(int64_t)v * n + u] = scale * (double)xi;
+            const double x = fmin(fmax((double)H[(int64_t)v * n + u] * inv, -1073741824.0), 1073741824.0);
+            xi = (int)__builtin_rint(x);
+            if (ext) {
+                // remainder in units of 2^-16: two balanced base-256 digits hold [-32896, 32639]
+                xj = (int)__builtin_rint((x - (double)xi) * 65536.0);
+                if (xj > 32639) {
+                    xi += 1;
+                    xj -= 65536;
+                }
+            }
+            if (H64) H64[(int64_t)v * n + u] = scale * ((double)xi + (double)xj * EXT_UNIT);
             if (Hint) Hint[(int64_t)v * n + u] = xi;
-            if (u == v) hdiag_int[u] = xi;
+            if (Jint) Jint[(int64_t)v * n + u] = (short)(xj + JBIAS);
+            if (u == v) {
+                hdiag_int[u] = xi;
+                hdiag_j[u] = xj;
+            }
         }
         int r = xi;
 #pragma unroll
@@ -109,10 +151,34 @@ __global__ __launch_bounds__(256) void hquant_kernel(const float* __restrict__ H
             r = (r - d) >> 8;
             pk[p] |= (uint32_t)(d & 255) << (8 * k);
         }
+        r = xj;
+#pragma unroll
+        for (int p = 4; p < 6; ++p) {
+            const int d = ((r + 128) & 255) - 128;
+            r = (r - d) >> 8;
+            pk[p] |= (uint32_t)(d & 255) << (8 * k);
+        }
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-        *reinterpret_cast<uint32_t*>(planes + ((int64_t)p * n + v) * nq + u0) = pk[p];
+    for (int p = 0; p < 6; ++p)
+        if (p < 4 || ext) *reinterpret_cast<uint32_t*>(planes + ((int64_t)p * n + v) * nq + u0) = pk[p];
+}
+
+// per-feature exponents for the W @ H product: e[u] = floor(log2(H_uu) / 2), so that H~[u][v] = H[u][v] 2^(-e_u - e_v) has a
+// diagonal in [1, 4) and, H being positive semi-definite, no entry above 4 (wh_gemm.hip)
+__global__ __launch_bounds__(256) void dexp_kernel(const int* __restrict__ hdiag_int, const int* __restrict__ hdiag_j,
+                                                  const TPrep* __restrict__ prep, int n, int* __restrict__ dexp,
+                                                  double* __restrict__ hdiag64) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n) return;
+    const double h = prep->scale * ((double)hdiag_int[u] + (double)hdiag_j[u] * EXT_UNIT);
+    hdiag64[u] = h;
+    int e = 0;
+    if (h > 0.0 && h < __builtin_inf()) {
+        const int lg = ilogb(h);  // floor(log2 h)
+        e = lg >= 0 ? lg / 2 : -((-lg + 1) / 2);  // floor(lg / 2)
+    }
+    dexp[u] = e;
 }
 
 // bits[(row * ng + g) * 16 + a] : bit l set  <=>  Q[row][64 g + l] == a
@@ -139,12 +205,19 @@ __global__ __launch_bounds__(256) void code_masks_kernel(const uint8_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __restrict__ planes,
+// NPL digit planes starting at plane P0: <4, 0> sums the 31-bit word I, <2, 4> the extension word J (into its own
+// Mpart; that launch leaves at once when the extension is off)
+template <int NPL, int P0>
+__global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __restrict__ planes_all,
                                                               const unsigned long long* __restrict__ bits,
                                                               const uint8_t* __restrict__ Q, int m, int n, int nq, int ng,
                                                               long long* __restrict__ Mpart, long long* __restrict__ stamps,
-                                                              const long long* __restrict__ changed, long long thr) {
+                                                              const long long* __restrict__ changed, long long thr,
+                                                              const TPrep* __restrict__ prep) {
     if (changed && *changed <= thr) return;
+    if (P0 != 0 && prep->ext == 0) return;
+    constexpr int BTILE = btile_bytes(NPL);
+    const int8_t* planes = planes_all + (int64_t)P0 * n * nq;
     extern __shared__ __align__(16) char smem[];
     long long st_pro = 0, st_loop = 0, st_flush = 0, st_t0 = 0;
     char* Bbuf = smem;                                                        // 2 x BTILE
@@ -167,8 +240,9 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 
     for (int i = lane; i < RW * 256; i += 64) Mrow[wv][i >> 8][i & 255] = 0;
 
-    // staging of one digit tile: 4 planes x VCH rows x 256 B = 2048 x 16 B, 4 per thread
-    constexpr int NE = 4 * VCH * UC16 / (TW * 64);  // 16-byte pieces of a digit tile per thread
+    // staging of one digit tile: NPL planes x VCH rows x 256 B (4 planes: 2048 x 16 B, 4 per thread)
+    constexpr int NE = NPL * VCH * UC16 / (TW * 64);  // 16-byte pieces of a digit tile per thread
+    static_assert(NE * TW * 64 == NPL * VCH * UC16, "digit tile must split evenly over the threads");
     uint4 stage[NE];
     auto gload = [&](int v0, int t) {
 #pragma unroll
@@ -207,11 +281,11 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
         const int v0 = c * VCH;
         const int t_first = (v0 + 1) / UT;
         if (t_first >= ntile) continue;
-        v16i acc[RW / 2][4];
+        v16i acc[RW / 2][NPL];
 #pragma unroll
         for (int p = 0; p < RW / 2; ++p)
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < NPL; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][d][r] = 0;
 
@@ -232,12 +306,12 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
             const int buf = (t - t_first) & 1;
             if (t + 1 < ntile) gload(v0, t + 1);
             const char* Bt = Bbuf + buf * BTILE + i32 * BROW + 16 * kb;
-            auto read_b = [&](int ks, int kh, v4i (&bf)[4]) {
+            auto read_b = [&](int ks, int kh, v4i (&bf)[NPL]) {
 #pragma unroll
-                for (int d = 0; d < 4; ++d)
+                for (int d = 0; d < NPL; ++d)
                     bf[d] = *reinterpret_cast<const v4i*>(Bt + d * (VCH * BROW) + ks * 64 + kh * 32);
             };
-            v4i bf[2][4];
+            v4i bf[2][NPL];
             read_b(0, 0, bf[0]);
 #pragma unroll
             for (int ks = 0; ks < KS64; ++ks) {
@@ -254,7 +328,7 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 #pragma unroll
                         for (int d = 0; d < 4; ++d) af[d] = (int)((((b16 >> (4 * d)) & 0xfu) * 0x00204081u) & 0x01010101u);
 #pragma unroll
-                        for (int d = 0; d < 4; ++d)
+                        for (int d = 0; d < NPL; ++d)
                             acc[p][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[hh & 1][d], acc[p][d], 0, 0, 0);
                     }
                 }
@@ -276,8 +350,9 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
                 for (int reg = 0; reg < 16; ++reg) {
                     const int i = (reg & 3) + 8 * (reg >> 2) + 4 * kb;  // (row of the pair, code)
                     const int h = i >> 4, a = i & 15;
-                    const long long val = (long long)acc[p][0][reg] + ((long long)acc[p][1][reg] << 8) +
-                                          ((long long)acc[p][2][reg] << 16) + ((long long)acc[p][3][reg] << 24);
+                    long long val = 0;
+#pragma unroll
+                    for (int d = 0; d < NPL; ++d) val += (long long)acc[p][d][reg] << (8 * d);
                     const uint32_t b = bq[h];
                     if (b < 16u && val != 0)
                         atomicAdd(reinterpret_cast<unsigned long long*>(&Mrow[wv][2 * p + h][a * 16 + b]),
@@ -331,10 +406,14 @@ __device__ __forceinline__ void wave_sync() {
 // full accumulation over the new indices gives.
 
 // Mstate[row] = F = M + M^T with M = sum_p Mpart[p][row]; Qprev = Q   (after a full accumulation)
+// is_lo: the sums of the extension word (own Mpart / Mstate; leaves at once when the extension is off; Qprev is the
+// other launch's business)
 __global__ __launch_bounds__(256) void m_reduce_kernel(const long long* __restrict__ Mpart, int m, long long* __restrict__ Mstate,
                                                       const uint8_t* __restrict__ Q, uint8_t* __restrict__ Qprev, int64_t qbytes,
-                                                      const long long* __restrict__ changed, long long thr) {
+                                                      const long long* __restrict__ changed, long long thr,
+                                                      const TPrep* __restrict__ prep, int is_lo) {
     if (changed && *changed <= thr) return;
+    if (is_lo && prep->ext == 0) return;
     const int64_t total = (int64_t)m * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t it = (i & ~255ll) | ((i & 15) << 4) | ((i >> 4) & 15);  // the transposed cell of the same row
@@ -343,6 +422,7 @@ __global__ __launch_bounds__(256) void m_reduce_kernel(const long long* __restri
         for (int p = 0; p < NP; ++p) s += Mpart[(int64_t)p * total + i] + Mpart[(int64_t)p * total + it];
         Mstate[i] = s;
     }
+    if (is_lo) return;
     const int64_t q16 = qbytes / 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < q16; i += (int64_t)gridDim.x * 256)
         reinterpret_cast<uint4*>(Qprev)[i] = reinterpret_cast<const uint4*>(Q)[i];
@@ -418,12 +498,19 @@ __global__ __launch_bounds__(QD_WAVES * 64) void q_diff_kernel(const uint8_t* __
 // S_e is a 16-bucket histogram of one row of Hint: lane-private buckets in LDS ([bucket][lane]: no conflicts), then
 // a transposed read sums each bucket over the lanes; the second sum is just 2 more entries per earlier change.
 constexpr int MU_WAVES = 4;  // 4096x4096 benchmark layer: 2 -> 0.224, 4 -> 0.210, 8 -> 0.250 ms per iteration
-__global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __restrict__ Hint, const uint8_t* __restrict__ Q,
+// HT = int: the 31-bit word (Hint -> Mstate), updates Qprev at the end; HT = short: the extension word (Jint ->
+// Mstate_lo), launched BEFORE the other one (it needs the old codes), leaves at once when the extension is off.
+template <typename HT>
+__global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const HT* __restrict__ Hint, const uint8_t* __restrict__ Q,
                                                                 uint8_t* __restrict__ Qprev, int m, int n,
                                                                 const uint16_t* __restrict__ chg, const int* __restrict__ chgcnt,
                                                                 long long* __restrict__ Mstate,
-                                                                const long long* __restrict__ changed, long long thr) {
+                                                                const long long* __restrict__ changed, long long thr,
+                                                                const TPrep* __restrict__ prep) {
     if (*changed > thr) return;  // the full accumulation runs instead
+    constexpr bool IS_LO = sizeof(HT) == 2;
+    constexpr int BIAS = IS_LO ? JBIAS : 0;  // the int16 copy of the extension word is stored biased
+    if (IS_LO && prep->ext == 0) return;
     extern __shared__ __align__(16) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = blockIdx.x;
@@ -443,7 +530,7 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
     // a dependent L2 / HBM round trip, so the next item's 16 KB are always in flight (16 x 16 B per lane) while the
     // current one is bucketed.
     constexpr int CH = 16;                       // int4 loads per lane and chunk: 64 * 16 * 4 = 4096 columns
-    const bool vec = (n & 3) == 0;               // rows of Hint are 16-byte aligned
+    const bool vec = !IS_LO && (n & 3) == 0;     // rows of Hint are 16-byte aligned (int32 only)
     const int nchunk = (n + 64 * CH * 4 - 1) / (64 * CH * 4);
     const int mycols = (cnt - wv + MU_WAVES - 1) / MU_WAVES;  // e = wv, wv + MU_WAVES, ..
     const int nitems = mycols * nchunk;
@@ -452,19 +539,19 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
     const int p_old = lane < cnt ? codes[pc] : 0, p_new = lane < cnt ? min((int)qn[pc], 15) : 0;
     auto load_item = [&](int it, int4 (&buf)[CH], int& corr) {
         const int e = wv + (it / nchunk) * MU_WAVES, k = it % nchunk;
-        const int* hrow = Hint + (int64_t)list[e] * n;
-        corr = (k == 0 && lane < e) ? hrow[pc] : 0;
+        const HT* hrow = Hint + (int64_t)list[e] * n;
+        corr = (k == 0 && lane < e) ? (int)hrow[pc] - BIAS : 0;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int x = 4 * (64 * (CH * k + j) + lane);
             int4 v = make_int4(0, 0, 0, 0);
             if (vec) {
-                if (x < n) v = *reinterpret_cast<const int4*>(hrow + x);
+                if (x < n) v = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(hrow) + x);
             } else {
-                if (x < n) v.x = hrow[x];
-                if (x + 1 < n) v.y = hrow[x + 1];
-                if (x + 2 < n) v.z = hrow[x + 2];
-                if (x + 3 < n) v.w = hrow[x + 3];
+                if (x < n) v.x = (int)hrow[x] - BIAS;
+                if (x + 1 < n) v.y = (int)hrow[x + 1] - BIAS;
+                if (x + 2 < n) v.z = (int)hrow[x + 2] - BIAS;
+                if (x + 3 < n) v.w = (int)hrow[x + 3] - BIAS;
             }
             buf[j] = v;
         }
@@ -484,7 +571,7 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
             }
             for (int e2 = 64 + lane; e2 < e; e2 += 64) {  // more than 64 changes in the row: rare
                 const int c2 = list[e2];
-                const long long v = Hint[(int64_t)c * n + c2];
+                const long long v = (long long)Hint[(int64_t)c * n + c2] - BIAS;
                 lds_add(&priv[min((int)qn[c2], 15) * 64 + lane], v);
                 lds_add(&priv[(int)codes[c2] * 64 + lane], -v);
             }
@@ -531,7 +618,8 @@ __global__ __launch_bounds__(MU_WAVES * 64) void m_update_kernel(const int* __re
     }
     __syncthreads();
     for (int i = tid; i < 256; i += MU_WAVES * 64) Fg[i] = Frow[i];
-    for (int e = tid; e < cnt; e += MU_WAVES * 64) qp[list[e]] = qn[list[e]];
+    if (!IS_LO)
+        for (int e = tid; e < cnt; e += MU_WAVES * 64) qp[list[e]] = qn[list[e]];
 }
 
 // The same move on the integer matrix cores (rows whose length is a multiple of 16).  The 16-bucket histograms of the
@@ -553,9 +641,9 @@ __device__ __forceinline__ uint32_t bytes_equal(uint32_t x, uint32_t pat) {  // 
     return (~t & 0x80808080u) >> 7;
 }
 
-template <int NT>
+template <int NT, int NPL>
 __device__ __forceinline__ void mu_group(const int8_t* __restrict__ planes, int n, int nq, const uint8_t* __restrict__ qp,
-                                         const int (&cj)[MG_TILES], int lane, int kb, int ke, v4i (&acc)[MG_TILES][4]) {
+                                         const int (&cj)[MG_TILES], int lane, int kb, int ke, v4i (&acc)[MG_TILES][6]) {
     const int i16 = lane & 15, kq = lane >> 4;
     const uint32_t pat = (uint32_t)i16 * 0x01010101u;
     const int64_t plane = (int64_t)n * nq;
@@ -563,18 +651,18 @@ __device__ __forceinline__ void mu_group(const int8_t* __restrict__ planes, int 
 #pragma unroll
     for (int t = 0; t < NT; ++t) bp[t] = planes + (int64_t)cj[t] * nq + 16 * kq;
     if (kb >= ke) return;
-    auto load = [&](int k0, uint4& cw, v4i (&bf)[NT][4]) {
+    auto load = [&](int k0, uint4& cw, v4i (&bf)[NT][NPL]) {
         cw = *reinterpret_cast<const uint4*>(qp + min(k0 + 16 * kq, n - 16));  // past n the digits are zero
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) bf[t][p] = *reinterpret_cast<const v4i*>(bp[t] + p * plane + k0);
+            for (int p = 0; p < NPL; ++p) bf[t][p] = *reinterpret_cast<const v4i*>(bp[t] + p * plane + k0);
     };
     // every step is one dependent round trip to L2 / Infinity Cache: D steps of operands are kept in flight
     constexpr int D = NT == 1 ? 4 : 2;
     uint4 cw[D];
-    v4i bf[D][NT][4];
-    auto step = [&](const uint4& c, const v4i (&b)[NT][4]) {
+    v4i bf[D][NT][NPL];
+    auto step = [&](const uint4& c, const v4i (&b)[NT][NPL]) {
         v4i af;
         af[0] = (int)bytes_equal(c.x, pat);
         af[1] = (int)bytes_equal(c.y, pat);
@@ -583,7 +671,7 @@ __device__ __forceinline__ void mu_group(const int8_t* __restrict__ planes, int 
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[t][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, b[t][p], acc[t][p], 0, 0, 0);
+            for (int p = 0; p < NPL; ++p) acc[t][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, b[t][p], acc[t][p], 0, 0, 0);
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) load(min(kb + 64 * d, ke - 64), cw[d], bf[d]);
@@ -596,22 +684,31 @@ __device__ __forceinline__ void mu_group(const int8_t* __restrict__ planes, int 
     }
 }
 
+// With the extension word on (prep->ext, uniform) the two extra digit planes ride along in the same pass and move the
+// second set of sums Mstate_lo; the pair / diagonal corrections come from Jint / hdiag_j.
 __global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8_t* __restrict__ planes, const int* __restrict__ Hint,
-                                                           const int* __restrict__ hdiag_int, const uint8_t* __restrict__ Q,
+                                                           const short* __restrict__ Jint,
+                                                           const int* __restrict__ hdiag_int, const int* __restrict__ hdiag_j,
+                                                           const uint8_t* __restrict__ Q,
                                                            uint8_t* __restrict__ Qprev, int m, int n, int nq,
                                                            const uint16_t* __restrict__ chg, const int* __restrict__ chgcnt,
-                                                           long long* __restrict__ Mstate, const long long* __restrict__ changed,
-                                                           long long thr) {
+                                                           long long* __restrict__ Mstate, long long* __restrict__ Mstate_lo,
+                                                           const long long* __restrict__ changed, long long thr,
+                                                           const TPrep* __restrict__ prep) {
     if (*changed > thr) return;  // the full accumulation runs instead
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int cnt = chgcnt[row];
     if (cnt == 0) return;
+    const bool ext = prep->ext != 0;
     __shared__ long long Frow[256];
+    __shared__ long long Flo[256];
     long long* Fg = Mstate + (int64_t)row * 256;
+    long long* Fgl = Mstate_lo + (int64_t)row * 256;
     uint8_t* qp = Qprev + (int64_t)row * n;
     const uint8_t* qn = Q + (int64_t)row * n;
     const uint16_t* list = chg + (int64_t)row * n;
     Frow[tid] = Fg[tid];
+    if (ext) Flo[tid] = Fgl[tid];
     // the row's changes (column, old code, new code): one parallel round of loads instead of dependent ones per use
     constexpr int CAP = 512;
     __shared__ uint16_t s_col[CAP];
@@ -630,12 +727,13 @@ __global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8
     const int kb = min(wv * kper, ksteps) * 64, ke = min((wv + 1) * kper, ksteps) * 64;  // this wave's columns
     auto lds_add = [&](long long* p, long long v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     // F[a_old][b] -= s, F[b][a_old] -= s, F[a_new][b] += s, F[b][a_new] += s
-    auto move = [&](int a_old, int a_new, int b, long long s) {
-        lds_add(&Frow[a_old * 16 + b], -s);
-        lds_add(&Frow[b * 16 + a_old], -s);
-        lds_add(&Frow[a_new * 16 + b], s);
-        lds_add(&Frow[b * 16 + a_new], s);
+    auto move_in = [&](long long* F, int a_old, int a_new, int b, long long s) {
+        lds_add(&F[a_old * 16 + b], -s);
+        lds_add(&F[b * 16 + a_old], -s);
+        lds_add(&F[a_new * 16 + b], s);
+        lds_add(&F[b * 16 + a_new], s);
     };
+    auto move = [&](int a_old, int a_new, int b, long long s) { move_in(Frow, a_old, a_new, b, s); };
     const int i16 = lane & 15, kq = lane >> 4;
     for (int g0 = 0; g0 < cnt; g0 += 16 * MG_TILES) {
         const int nt = min(MG_TILES, (cnt - g0 + 15) >> 4);
@@ -645,13 +743,18 @@ __global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8
             const int e = g0 + 16 * t + i16;
             cj[t] = col_of(e < cnt ? e : g0);  // padding columns repeat a valid one; their sums are dropped below
         }
-        v4i acc[MG_TILES][4];
+        v4i acc[MG_TILES][6];
 #pragma unroll
         for (int t = 0; t < MG_TILES; ++t)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[t][p] = v4i{0, 0, 0, 0};
-        if (nt == 1) mu_group<1>(planes, n, nq, qp, cj, lane, kb, ke, acc);
-        else mu_group<2>(planes, n, nq, qp, cj, lane, kb, ke, acc);
+            for (int p = 0; p < 6; ++p) acc[t][p] = v4i{0, 0, 0, 0};
+        if (ext) {
+            if (nt == 1) mu_group<1, 6>(planes, n, nq, qp, cj, lane, kb, ke, acc);
+            else mu_group<2, 6>(planes, n, nq, qp, cj, lane, kb, ke, acc);
+        } else {
+            if (nt == 1) mu_group<1, 4>(planes, n, nq, qp, cj, lane, kb, ke, acc);
+            else mu_group<2, 4>(planes, n, nq, qp, cj, lane, kb, ke, acc);
+        }
         // D layout: lane (j = lane & 15, kq) holds S[b = 4 kq + r][change j], r = 0..3
 #pragma unroll
         for (int t = 0; t < MG_TILES; ++t) {
@@ -659,6 +762,7 @@ __global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8
             if (t < nt && e < cnt) {
                 const int a_old = old_of(e), a_new = new_of(e);
                 const long long self = wv == 0 ? (long long)hdiag_int[cj[t]] : 0;
+                const long long self_lo = (ext && wv == 0) ? (long long)hdiag_j[cj[t]] : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int b = 4 * kq + r;
@@ -666,6 +770,11 @@ __global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8
                                    ((long long)acc[t][3][r] << 24);
                     if (b == a_old) sb -= self;  // the column itself is not part of its own histogram (taken out once)
                     if (sb != 0) move(a_old, a_new, b, sb);
+                    if (ext) {
+                        long long sl = (long long)acc[t][4][r] + ((long long)acc[t][5][r] << 8);
+                        if (b == a_old) sl -= self_lo;
+                        if (sl != 0) move_in(Flo, a_old, a_new, b, sl);
+                    }
                 }
             }
         }
@@ -680,15 +789,25 @@ __global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8
             move(a_old, a_new, new_of(e2), v);
             move(a_old, a_new, old_of(e2), -v);
         }
+        if (ext) {
+            const long long vl = (long long)Jint[(int64_t)col_of(e) * n + col_of(e2)] - JBIAS;
+            if (vl != 0) {
+                const int a_old = old_of(e), a_new = new_of(e);
+                move_in(Flo, a_old, a_new, new_of(e2), vl);
+                move_in(Flo, a_old, a_new, old_of(e2), -vl);
+            }
+        }
     }
     __syncthreads();
     Fg[tid] = Frow[tid];
+    if (ext) Fgl[tid] = Flo[tid];
     for (int e = tid; e < cnt; e += MG_WAVES * 64) qp[list[e]] = qn[list[e]];
 }
 
 template <typename WHT>
-__global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict__ Mpart, const TPrep* __restrict__ prep,
-                                                     const int* __restrict__ hdiag_int, const WHT* __restrict__ WH,
+__global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict__ Mpart, const long long* __restrict__ Mpart_lo,
+                                                     const TPrep* __restrict__ prep, const int* __restrict__ hdiag_int,
+                                                     const int* __restrict__ hdiag_j, const WHT* __restrict__ WH,
                                                      const double* __restrict__ wHw, const uint8_t* __restrict__ Q, int m,
                                                      int n, int V, double rcond, float* __restrict__ T_out,
                                                      float* __restrict__ A_out, float* __restrict__ b_out,
@@ -701,6 +820,8 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     __shared__ double Es[4][16][JS];
     __shared__ double A0[4][16][JS];       // unrounded A (for the loss), also scratch for the bucket sums
     __shared__ long long Di[4][16][JS];    // lane-private integer buckets of diag(H), then scratch for the transpose
+    // the same for the extension word: aliases Es, which is first written after the bucket sums have been consumed
+    long long(*Dj)[16][JS] = reinterpret_cast<long long(*)[16][JS]>(&Es[0][0][0]);
     __shared__ double CS[4][8][2];
     __shared__ double Coef[4][16];
 
@@ -712,6 +833,7 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     double(*E)[JS] = Es[rs];
     double(*B0)[JS] = A0[rs];
     const double scale = prep->scale;
+    const bool ext = prep->ext != 0;  // uniform
 
     // ---- b_i[a] = sum_{u in a} WH[row][u] and D[a] = sum_{u in a} H[u][u]: lane l takes u = 16 t + l into its own
     //      16 buckets (no atomics), then lane a sums bucket a over the lanes in fixed order
@@ -719,6 +841,7 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     for (int a = 0; a < 16; ++a) {
         B0[l][a] = 0.0;
         Di[rs][l][a] = 0;
+        Dj[rs][l][a] = 0;
     }
     {
         const uint8_t* q = Q + (int64_t)rowc * n;
@@ -745,14 +868,17 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
             B0[l][a] += (double)wh[u];
             Di[rs][l][a] += (long long)hdiag_int[u];
         }
+        if (ext)
+            for (int u = l; u < n; u += 16) Dj[rs][l][min((int)q[u], 15)] += (long long)hdiag_j[u];
     }
     wave_sync();
     double bsum = 0.0;
-    long long dsum = 0;
+    long long dsum = 0, dsum_lo = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         bsum += B0[k][l];
         dsum += Di[rs][k][l];
+        dsum_lo += Dj[rs][k][l];
     }
     wave_sync();
 
@@ -768,13 +894,30 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     }
 #pragma unroll
     for (int a = 0; a < 16; ++a) Di[rs][a][l] = col[a];
+    if (ext) {  // the extension word's sums, same layout
+#pragma unroll
+        for (int a = 0; a < 16; ++a) col[a] = 0;
+        for (int p = 0; p < (sym_in ? 1 : nparts); ++p) {
+            const long long* src = Mpart_lo + ((int64_t)p * m + rowc) * 256;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) col[a] += src[a * 16 + l];
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) Dj[rs][a][l] = col[a];
+    }
     wave_sync();
     double colA[16], colA0[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         long long x = sym_in ? Di[rs][a][l] : Di[rs][a][l] + Di[rs][l][a];
         if (a == l) x += dsum;
-        colA0[a] = scale * (double)x;
+        double xd = (double)x;
+        if (ext) {
+            long long xl = sym_in ? Dj[rs][a][l] : Dj[rs][a][l] + Dj[rs][l][a];
+            if (a == l) xl += dsum_lo;
+            xd += (double)xl * EXT_UNIT;
+        }
+        colA0[a] = scale * xd;
         colA[a] = (double)(float)colA0[a];  // the reference holds A and b in fp32
     }
     const double bl0 = bsum;
@@ -1069,14 +1212,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// GANQ_WH_F64=1 (read once): W @ H_fixed by the fp64 GEMM instead of the split-fp16 product -- the A/B reference
-static bool wh_use_f64_gemm() {
-    static const bool f64 = [] {
-        const char* e = getenv("GANQ_WH_F64");
-        return e && e[0] == '1';
-    }();
-    return f64;
-}
+// option GANQ_WH_F64=1: W @ H_fixed by the fp64 GEMM instead of the split-fp16 product -- the A/B reference
+static bool wh_use_f64_gemm() { return opt_get(OPT_WH_F64) == 1; }
 
 TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
     TLayout lo;
@@ -1089,10 +1226,13 @@ TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
         return o;
     };
     lo.off_prep = take(sizeof(TPrep));
-    lo.off_planes = take((size_t)4 * n * lo.nq);
+    lo.off_planes = take((size_t)6 * n * lo.nq);  // 4 digit planes of I + 2 of the extension word J
     lo.off_hdiag = take((size_t)n * sizeof(int));
+    lo.off_hdiag_j = take((size_t)n * sizeof(int));
     lo.off_bits = take((size_t)m * lo.ng * 16 * sizeof(unsigned long long));
     lo.off_mpart = take((size_t)NP * m * 256 * sizeof(long long));
+    lo.off_mpart_lo = take((size_t)NP * m * 256 * sizeof(long long));
+    lo.off_mstate_lo = lo.off_jint = lo.off_dexp = lo.off_hdiag64 = 0;
     lo.off_h64 = lo.off_wh64 = lo.off_whw = lo.off_lossrows = 0;
     lo.off_hint = lo.off_qprev = lo.off_mstate = lo.off_chg = lo.off_chgcnt = 0;
     lo.off_wp = lo.off_hp = lo.off_rexp = lo.off_wlo = 0;
@@ -1101,6 +1241,10 @@ TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
         lo.off_hint = take((size_t)n * n * sizeof(int));
         lo.off_qprev = take((size_t)m * n);
         lo.off_mstate = take((size_t)m * 256 * sizeof(long long));
+        lo.off_mstate_lo = take((size_t)m * 256 * sizeof(long long));
+        lo.off_jint = take((size_t)n * n * sizeof(short));
+        lo.off_dexp = take((size_t)n * sizeof(int));
+        lo.off_hdiag64 = take((size_t)n * sizeof(double));
         lo.off_chg = take((size_t)m * n * sizeof(uint16_t));
         lo.off_chgcnt = take((size_t)m * sizeof(int) + 64);  // counts per row, then the 8-byte total
         lo.off_active = take(((size_t)m + 1) * sizeof(int));  // rows that changed in the last iteration, their number
@@ -1121,10 +1265,11 @@ TLayout t_layout(int64_t m, int64_t n, bool with_f64) {
     return lo;
 }
 
-__global__ __launch_bounds__(256) void hfixed_kernel(const int* __restrict__ Hint, const TPrep* __restrict__ prep, int64_t total,
-                                                    double* __restrict__ out) {
+__global__ __launch_bounds__(256) void hfixed_kernel(const int* __restrict__ Hint, const short* __restrict__ Jint,
+                                                    const TPrep* __restrict__ prep, int64_t total, double* __restrict__ out) {
+    const bool ext = prep->ext != 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
-        out[i] = prep->scale * (double)Hint[i];
+        out[i] = prep->scale * ((double)Hint[i] + (ext ? (double)((int)Jint[i] - JBIAS) * EXT_UNIT : 0.0));
 }
 
 // rows whose indices changed in this iteration (ascending) and their number.  A row without a change has reached a
@@ -1162,15 +1307,17 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
     TPrep* prep = reinterpret_cast<TPrep*>(ws + lo.off_prep);
     int8_t* planes = reinterpret_cast<int8_t*>(ws + lo.off_planes);
     int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
+    int* hdiag_j = reinterpret_cast<int*>(ws + lo.off_hdiag_j);
     double* H64 = (with_f64 && lo.off_h64) ? reinterpret_cast<double*>(ws + lo.off_h64) : nullptr;
     ProfScope prof(KID_T_PREP, stream);
     GANQ_HIP_CHECK(hipMemsetAsync(prep, 0, sizeof(TPrep), stream));
     hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, H, n * n, prep);
-    hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(1), 0, stream, prep);
+    hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(256), 0, stream, H, (int)n, prep, (int)opt_get(OPT_H_EXT));
     const int64_t quads = n * lo.nq / 4;
     int* Hint = with_f64 ? reinterpret_cast<int*>(ws + lo.off_hint) : nullptr;
+    short* Jint = with_f64 ? reinterpret_cast<short*>(ws + lo.off_jint) : nullptr;
     hipLaunchKernelGGL(hquant_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, H, (int)n, (int)lo.nq, prep,
-                       planes, hdiag, H64, Hint);
+                       planes, hdiag, hdiag_j, H64, Hint, Jint);
     GANQ_LAUNCH_CHECK();
     if (with_f64) {
         // change counter of the incremental bucket sums: zero once, every t_solve leaves it zero again
@@ -1182,8 +1329,12 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
             hipLaunchKernelGGL(gemm_f64_kernel, dim3(tiles), dim3(256), 0, stream, W, H64, WH64, (int)m, (int)n, (int)n);
         } else {
             const WhLayout wl = wh_layout(m, n);
-            int rc = wh_gemm(W, Hint, &prep->scale, m, n, wl, ws + lo.off_wp, ws + lo.off_hp, reinterpret_cast<int*>(ws + lo.off_rexp),
-                             reinterpret_cast<int*>(ws + lo.off_wlo), WH64, stream);
+            int* dexp = reinterpret_cast<int*>(ws + lo.off_dexp);
+            double* hdiag64 = reinterpret_cast<double*>(ws + lo.off_hdiag64);
+            hipLaunchKernelGGL(dexp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, hdiag, hdiag_j, prep, (int)n, dexp,
+                               hdiag64);
+            int rc = wh_gemm(W, Hint, Jint, &prep->ext, dexp, hdiag64, &prep->scale, m, n, wl, ws + lo.off_wp, ws + lo.off_hp,
+                             reinterpret_cast<int*>(ws + lo.off_rexp), reinterpret_cast<int*>(ws + lo.off_wlo), WH64, stream);
             if (rc) return rc;
         }
         hipLaunchKernelGGL(whw_kernel, dim3((unsigned)m), dim3(256), 0, stream, W, WH64, (int)m, (int)n, wHw);
@@ -1198,19 +1349,21 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
     TPrep* prep = reinterpret_cast<TPrep*>(ws + lo.off_prep);
     int8_t* planes = reinterpret_cast<int8_t*>(ws + lo.off_planes);
     int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
+    int* hdiag_j = reinterpret_cast<int*>(ws + lo.off_hdiag_j);
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws + lo.off_bits);
     long long* mpart = reinterpret_cast<long long*>(ws + lo.off_mpart);
-    // test hooks: GANQ_T_FULL=1 -> stateless full accumulation every call; GANQ_T_INCR_THR=<count> -> device-side
-    // fallback threshold (changed indices per layer) instead of m*n/16
-    const char* env_full = getenv("GANQ_T_FULL");
-    const char* env_thr = getenv("GANQ_T_INCR_THR");
-    const bool stateful = iter >= 0 && lo.off_hint != 0 && !(env_full && env_full[0] == '1');
+    long long* mpart_lo = reinterpret_cast<long long*>(ws + lo.off_mpart_lo);
+    // test switches (runtime.hip): GANQ_T_FULL=1 -> stateless full accumulation every call; GANQ_T_INCR_THR=<count> ->
+    // device-side fallback threshold (changed indices per layer) instead of m*n/16
+    const long long opt_thr = opt_get(OPT_T_INCR_THR);
+    const bool stateful = iter >= 0 && lo.off_hint != 0 && opt_get(OPT_T_FULL) != 1;
     long long* mstate = stateful ? reinterpret_cast<long long*>(ws + lo.off_mstate) : nullptr;
+    long long* mstate_lo = stateful ? reinterpret_cast<long long*>(ws + lo.off_mstate_lo) : nullptr;
     uint8_t* qprev = stateful ? reinterpret_cast<uint8_t*>(ws + lo.off_qprev) : nullptr;
     int* chgcnt = stateful ? reinterpret_cast<int*>(ws + lo.off_chgcnt) : nullptr;
     long long* changed = stateful ? reinterpret_cast<long long*>(ws + lo.off_chgcnt + align_up((size_t)m * sizeof(int), 8)) : nullptr;
     // more than 1/16 of all indices changed: the full accumulation is cheaper (decided on the device, no host sync)
-    const long long thr = env_thr ? atoll(env_thr) : (long long)((m * n) >> 4);
+    const long long thr = opt_thr >= 0 ? opt_thr : (long long)((m * n) >> 4);
     const long long* gate = nullptr;  // null: the full path runs unconditionally
     if (stateful && iter > 0) {
         ProfScope prof(KID_T_INCR, stream);
@@ -1218,21 +1371,23 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         hipLaunchKernelGGL(q_diff_kernel, dim3((unsigned)((m + QD_WAVES - 1) / QD_WAVES)), dim3(QD_WAVES * 64), 0, stream, Q, qprev, (int)m, (int)n, chg, chgcnt,
                            changed);
         const size_t usmem = (size_t)(256 + MU_WAVES * 16 * 64) * sizeof(long long) + align_up((size_t)n, 16);
-        static size_t attr_usmem = 0;
-        if (usmem > 64 * 1024 && usmem > attr_usmem) {
-            GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(m_update_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)usmem));
-            attr_usmem = usmem;
-        }
-        static const bool mu_lds = [] { const char* e = getenv("GANQ_MUPDATE_LDS"); return e && e[0] == '1'; }();  // A/B hook
+        const bool mu_lds = opt_get(OPT_MUPDATE_LDS) == 1;  // A/B switch
+        const int* Hint = reinterpret_cast<const int*>(ws + lo.off_hint);
+        const short* Jint = reinterpret_cast<const short*>(ws + lo.off_jint);
         if ((n & 15) == 0 && !mu_lds)
-            hipLaunchKernelGGL(m_update_mfma_kernel, dim3((unsigned)m), dim3(MG_WAVES * 64), 0, stream, planes,
-                               reinterpret_cast<const int*>(ws + lo.off_hint), hdiag, Q, qprev, (int)m, (int)n, (int)lo.nq, chg,
-                               chgcnt, mstate, changed, thr);
-        else
-            hipLaunchKernelGGL(m_update_kernel, dim3((unsigned)m), dim3(MU_WAVES * 64), usmem, stream,
-                               reinterpret_cast<const int*>(ws + lo.off_hint), Q, qprev, (int)m, (int)n, chg, chgcnt, mstate,
-                               changed, thr);
+            hipLaunchKernelGGL(m_update_mfma_kernel, dim3((unsigned)m), dim3(MG_WAVES * 64), 0, stream, planes, Hint, Jint, hdiag,
+                               hdiag_j, Q, qprev, (int)m, (int)n, (int)lo.nq, chg, chgcnt, mstate, mstate_lo, changed, thr, prep);
+        else {
+            int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(m_update_kernel<int>), usmem);
+            if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(m_update_kernel<short>), usmem);
+            if (rc) return rc;
+            // the extension word first (it needs the old codes; leaves at once when the extension is off), then the
+            // 31-bit word, which also brings Qprev up to date
+            hipLaunchKernelGGL(m_update_kernel<short>, dim3((unsigned)m), dim3(MU_WAVES * 64), usmem, stream, Jint, Q, qprev, (int)m,
+                               (int)n, chg, chgcnt, mstate_lo, changed, thr, prep);
+            hipLaunchKernelGGL(m_update_kernel<int>, dim3((unsigned)m), dim3(MU_WAVES * 64), usmem, stream, Hint, Q, qprev, (int)m,
+                               (int)n, chg, chgcnt, mstate, changed, thr, prep);
+        }
         GANQ_LAUNCH_CHECK();
         gate = changed;
     }
@@ -1243,21 +1398,24 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
                            (int)lo.ng, bits, gate, thr);
     }
     GANQ_LAUNCH_CHECK();
-    static bool attr_set = false;
-    const size_t smem = 2 * (size_t)BTILE + (size_t)TW * RW * 256 * sizeof(long long);
-    if (!attr_set) {
-        GANQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(onehot_accum_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+    const size_t smem = 2 * (size_t)btile_bytes(4) + (size_t)TW * RW * 256 * sizeof(long long);
+    const size_t smem_lo = 2 * (size_t)btile_bytes(2) + (size_t)TW * RW * 256 * sizeof(long long);
+    {
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(onehot_accum_kernel<4, 0>), smem);
+        if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(onehot_accum_kernel<2, 4>), smem_lo);
+        if (rc) return rc;
     }
     {
         ProfScope prof(KID_SHT_ACCUM, stream);
         const int nrg = (int)((m + TR - 1) / TR);
-        static const bool dbg = getenv("GANQ_ACCUM_DEBUG") != nullptr;  // developer timing experiment
+        const bool dbg = opt_get(OPT_ACCUM_DEBUG) == 1;  // developer timing experiment
         long long* stamps = nullptr;
         if (dbg) (void)hipMalloc(&stamps, 64);
-        hipLaunchKernelGGL(onehot_accum_kernel, dim3((unsigned)(nrg * NP)), dim3(TW * 64), smem, stream, planes, bits, Q, (int)m,
-                           (int)n, (int)lo.nq, (int)lo.ng, mpart, stamps, gate, thr);
+        hipLaunchKernelGGL((onehot_accum_kernel<4, 0>), dim3((unsigned)(nrg * NP)), dim3(TW * 64), smem, stream, planes, bits, Q, (int)m,
+                           (int)n, (int)lo.nq, (int)lo.ng, mpart, stamps, gate, thr, prep);
+        // the extension word's planes into their own partial sums (leaves at once when the extension is off)
+        hipLaunchKernelGGL((onehot_accum_kernel<2, 4>), dim3((unsigned)(nrg * NP)), dim3(TW * 64), smem_lo, stream, planes, bits, Q,
+                           (int)m, (int)n, (int)lo.nq, (int)lo.ng, mpart_lo, static_cast<long long*>(nullptr), gate, thr, prep);
         if (stamps) {
             long long h[3];
             (void)hipStreamSynchronize(stream);
@@ -1265,26 +1423,29 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
             (void)hipFree(stamps);
             fprintf(stderr, "[onehot_accum stamps] wg0 wave0: prologue %lld, tile loop %lld, flush %lld cycles\n", h[0], h[1], h[2]);
         }
-        if (stateful)
-            hipLaunchKernelGGL(m_reduce_kernel, dim3(1024), dim3(256), 0, stream, mpart, (int)m, mstate, Q, qprev, m * n, gate, thr);
+        if (stateful) {
+            hipLaunchKernelGGL(m_reduce_kernel, dim3(1024), dim3(256), 0, stream, mpart, (int)m, mstate, Q, qprev, m * n, gate, thr, prep, 0);
+            hipLaunchKernelGGL(m_reduce_kernel, dim3(256), dim3(256), 0, stream, mpart_lo, (int)m, mstate_lo, Q, qprev, m * n, gate, thr,
+                               prep, 1);
+        }
     }
     GANQ_LAUNCH_CHECK();
     {
         ProfScope prof(KID_T_SOLVE, stream);
         const dim3 grid((unsigned)((m + 3) / 4));
-        const char* env_jac = getenv("GANQ_T_JACOBI");  // test hook: 1 -> every row by the Jacobi eigen-solve
-        const int allow_fast = !(env_jac && env_jac[0] == '1');
+        const int allow_fast = opt_get(OPT_T_JACOBI) != 1;  // test switch: 1 -> every row by the Jacobi eigen-solve
         const long long* msrc = stateful ? mstate : mpart;
+        const long long* msrc_lo = stateful ? mstate_lo : mpart_lo;
         const int nparts = stateful ? 0 : NP;  // 0: one part that is already symmetric
         if (WH32) {
-            hipLaunchKernelGGL(t_solve_kernel<float>, grid, dim3(64), 0, stream, msrc, prep, hdiag, WH32,
+            hipLaunchKernelGGL(t_solve_kernel<float>, grid, dim3(64), 0, stream, msrc, msrc_lo, prep, hdiag, hdiag_j, WH32,
                                static_cast<const double*>(nullptr), Q, (int)m, (int)n, V, rcond, T_out, A_out, b_out,
                                static_cast<double*>(nullptr), nparts, static_cast<long long*>(nullptr), allow_fast);
         } else {
             const double* WH64 = reinterpret_cast<const double*>(ws + lo.off_wh64);
             const double* wHw = reinterpret_cast<const double*>(ws + lo.off_whw);
             double* loss_rows = reinterpret_cast<double*>(ws + lo.off_lossrows);
-            hipLaunchKernelGGL(t_solve_kernel<double>, grid, dim3(64), 0, stream, msrc, prep, hdiag, WH64, wHw, Q, (int)m,
+            hipLaunchKernelGGL(t_solve_kernel<double>, grid, dim3(64), 0, stream, msrc, msrc_lo, prep, hdiag, hdiag_j, WH64, wHw, Q, (int)m,
                                (int)n, V, rcond, T_out, A_out, b_out, loss_mode ? loss_rows : nullptr, nparts, changed, allow_fast);
             if (loss_mode == 2) hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, loss_rows, (int)m, loss_out);
         }
@@ -1298,9 +1459,8 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
 int t_active_rows(int64_t m, const TLayout& lo, char* ws, const int** list, const int** count, hipStream_t stream) {
     *list = nullptr;
     *count = nullptr;
-    const char* env_full = getenv("GANQ_T_FULL");
-    const char* env_all = getenv("GANQ_SOLVE_ALL_ROWS");  // test hook: never skip a row in the S-solve
-    if (lo.off_hint == 0 || lo.off_active == 0 || (env_full && env_full[0] == '1') || (env_all && env_all[0] == '1')) return 0;
+    // GANQ_SOLVE_ALL_ROWS=1 (test switch): never skip a row in the S-solve
+    if (lo.off_hint == 0 || lo.off_active == 0 || opt_get(OPT_T_FULL) == 1 || opt_get(OPT_SOLVE_ALL_ROWS) == 1) return 0;
     int* l = reinterpret_cast<int*>(ws + lo.off_active);
     int* c = l + m;
     hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const int*>(ws + lo.off_chgcnt), (int)m, l, c);
@@ -1328,8 +1488,9 @@ extern "C" int ganq_debug_wh_product(const float* W, const float* H, int64_t m, 
         hipError_t e = hipMemcpyAsync(WH_out, ws + lo.off_wh64, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, stream);
         if (e == hipSuccess && Hfixed_out) {
             const int* Hint = reinterpret_cast<const int*>(ws + lo.off_hint);
-            hipLaunchKernelGGL(hfixed_kernel, dim3(1024), dim3(256), 0, stream, Hint, reinterpret_cast<const TPrep*>(ws + lo.off_prep),
-                               n * n, Hfixed_out);
+            const short* Jint = reinterpret_cast<const short*>(ws + lo.off_jint);
+            hipLaunchKernelGGL(hfixed_kernel, dim3(1024), dim3(256), 0, stream, Hint, Jint,
+                               reinterpret_cast<const TPrep*>(ws + lo.off_prep), n * n, Hfixed_out);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) rc = fail(-4, "ganq_debug_wh_product: %s", hipGetErrorString(e));

@@ -11,8 +11,11 @@ struct WhLayout {
 
 WhLayout wh_layout(int64_t m, int64_t n);
 
-// WH[m,n] (fp64) = W[m,n] (fp32) @ (hscale * Hint[n,n]) with Hint symmetric; all pointers device memory
-int wh_gemm(const float* W, const int* Hint, const double* hscale, int64_t m, int64_t n, const WhLayout& lo, char* wp, char* hp,
-            int* rexp, int* wlo_any, double* WH, hipStream_t stream);
+// WH[m,n] (fp64) = W[m,n] (fp32) @ H_fixed, H_fixed = hscale * (Hint + Jint / 65536) symmetric (Jint used when *ext != 0),
+// dexp[n] = per-feature exponents of the symmetric scaling (floor(log2 H_uu / 2)), hdiag64[n] = diag(H_fixed) (added
+// exactly, outside the matrix product); all pointers device memory
+int wh_gemm(const float* W, const int* Hint, const short* Jint, const int* ext, const int* dexp, const double* hdiag64,
+            const double* hscale, int64_t m, int64_t n, const WhLayout& lo, char* wp, char* hp, int* rexp, int* wlo_any, double* WH,
+            hipStream_t stream);
 
 }  // namespace ganq

@@ -1,12 +1,23 @@
 // W @ H_fixed for the T-update (reference ganq.py:590, `W @ H` in fp32) on the fp16 matrix cores.
 //
 // Both operands are split into two fp16 pieces, x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits
-// per element (the reference multiplies fp32 values, 24 bits), after an exact power-of-two scaling that puts the row
-// maximum of W and the maximum of H at 2^14..2^15 (fp16 has 5 exponent bits).  The product is
+// per element (the reference multiplies fp32 values, 24 bits), after exact power-of-two scalings that keep everything
+// inside fp16's 5 exponent bits whatever the dynamic range of the activations:
+//   * H is scaled SYMMETRICALLY, H~[u][v] = H[u][v] 2^(-e_u - e_v) with e_u = floor(log2(H_uu) / 2): its diagonal lies in
+//     [1, 4) and, H being positive semi-definite, no entry exceeds 4 -- a massive-activation feature (H_ii 10^6 x the
+//     typical one) would otherwise push the typical row of H into fp16's subnormals;
+//   * W takes the inverse column scaling, W~[i][v] = W[i][v] 2^(e_v), then a per-row scale puts the row maximum at
+//     2^14..2^15;  W H = (W~ H~) with column u of the result scaled back by 2^(e_u).
+//   * the DIAGONAL of H is taken out of the matrix product and added exactly in fp64, W H = W offdiag(H) + W diag(H): the
+//     term w_u H_uu is the bulk of (W H)[i][u], and the closed-form loss of the T-update (dist = w^T H w - 2 t^T b + t^T A t,
+//     a difference ~10^3 smaller than its terms) magnifies whatever rounding it carries.
+// The product is
 //     W H  ~=  Whi Hhi + Whi Hlo + Wlo Hhi          (Wlo Hlo is below 2^-22 of the result and dropped),
 // three v_mfma_f32_32x32x16_f16 per fragment pair into one fp32 accumulator; products of fp16 values are exact in
-// fp32, so the rounding left is that of the fp32 accumulation -- the same class of error as the reference's fp32 GEMM
-// (measured: 3e-7 relative on W H, 4e-8 on the codebook, against 1e-5 allowed).  A module whose weights are fp16
+// fp32, so the rounding left is that of the fp32 accumulation -- the same class of error as the reference's fp32 GEMM;
+// every WFLUSH k tiles (256 columns) the fp32 accumulators are added into fp64 ones and cleared, which keeps the
+// accumulation error 4x below that of one fp32 chain over n = 4096 (the closed-form loss of the T-update magnifies the
+// error of W H by ~10^3: dist = w^T H w - 2 t^T b + t^T A t).  A module whose weights are fp16
 // values has Wlo == 0: the split kernel records that per 128-row block and the third product and its loads are skipped.
 // H is symmetric, so both operands are read "row x k" and k is the contiguous direction of both.
 //
@@ -28,27 +39,29 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 constexpr int WT = 128;               // rows per operand block
 constexpr int WK = 32;                // k per tile
 constexpr int WIMG = WT * WK * 2;     // bytes of one piece of one tile (8 KB)
+constexpr int WFLUSH = 8;             // k tiles between two flushes of the fp32 accumulators into fp64 (power of two)
 
 __device__ __forceinline__ int64_t wh_chunk_offset(int r, int c) {  // inside one piece image
     return (int64_t)r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
 }
 
-// one workgroup per (padded) row of W: row maximum -> power-of-two scale, then the two pieces of every 8-k chunk
-__global__ __launch_bounds__(256) void wh_split_w_kernel(const float* __restrict__ W, int m, int n, int KT, char* __restrict__ Wp,
-                                                        int* __restrict__ rexp, int* __restrict__ wlo_any) {
+// one workgroup per (padded) row of W: column scaling 2^(dexp[u]), row maximum -> power-of-two scale, then the two
+// pieces of every 8-k chunk
+__global__ __launch_bounds__(256) void wh_split_w_kernel(const float* __restrict__ W, const int* __restrict__ dexp, int m, int n,
+                                                        int KT, char* __restrict__ Wp, int* __restrict__ rexp,
+                                                        int* __restrict__ wlo_any) {
     __shared__ float sh[4];
     const int r = blockIdx.x, rb = r >> 7, rr = r & 127;
     const float* w = W + (int64_t)min(r, m - 1) * n;
     float mx = 0.0f;
     if (r < m)
-        for (int u = threadIdx.x; u < n; u += 256) mx = fmaxf(mx, fabsf(w[u]));
+        for (int u = threadIdx.x; u < n; u += 256) mx = fmaxf(mx, fabsf(ldexpf(w[u], dexp[u])));
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     int sft = 0;
     if (mx > 0.0f && mx < __builtin_inff()) sft = 14 - max(ilogbf(mx), -100);  // mx * 2^sft in [2^14, 2^15)
-    const float sc = ldexpf(1.0f, sft);
     if (threadIdx.x == 0 && r < m) rexp[r] = sft;
     bool any = false;
     for (int ci = threadIdx.x; ci < KT * 4; ci += 256) {
@@ -56,7 +69,7 @@ __global__ __launch_bounds__(256) void wh_split_w_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int u = ci * 8 + k;
-            const float x = (r < m && u < n) ? w[u] * sc : 0.0f;
+            const float x = (r < m && u < n) ? ldexpf(w[u], dexp[u] + sft) : 0.0f;
             const _Float16 h = (_Float16)x;
             const _Float16 l = (_Float16)(x - (float)h);
             hi[k] = h;
@@ -70,16 +83,28 @@ __global__ __launch_bounds__(256) void wh_split_w_kernel(const float* __restrict
     if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(&wlo_any[rb], 1);
 }
 
-// one workgroup per (padded) row of the fixed-point H: x = integer * 2^-16, |x| <= 2^14
-__global__ __launch_bounds__(256) void wh_split_h_kernel(const int* __restrict__ Hint, int n, int KT, char* __restrict__ Hp) {
+// one workgroup per (padded) row of the fixed-point H = hscale * (I + J / 65536) (J: the extension word, when on):
+// x = H[r][u] 2^(12 - e_r - e_u), |x| < 2^14
+__global__ __launch_bounds__(256) void wh_split_h_kernel(const int* __restrict__ Hint, const short* __restrict__ Jint,
+                                                        const int* __restrict__ ext, const int* __restrict__ dexp,
+                                                        const double* __restrict__ hscale, int n, int KT, char* __restrict__ Hp) {
     const int r = blockIdx.x, rb = r >> 7, rr = r & 127;
-    const int* h = Hint + (int64_t)min(r, n - 1) * n;
+    const int rc = min(r, n - 1);
+    const int* h = Hint + (int64_t)rc * n;
+    const short* hj = Jint + (int64_t)rc * n;
+    const bool use_j = *ext != 0;
+    const double hs = *hscale;
+    const int er = dexp[rc];
     for (int ci = threadIdx.x; ci < KT * 4; ci += 256) {
         h8v hi, lo;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int u = ci * 8 + k;
-            const double x = (r < n && u < n) ? (double)h[u] * (1.0 / 65536.0) : 0.0;
+            double x = 0.0;
+            if (r < n && u < n && u != r) {  // the diagonal is added exactly by the GEMM's epilogue
+                const double fx = (double)h[u] + (use_j ? (double)((int)hj[u] - 128) * (1.0 / 65536.0) : 0.0);  // stored biased
+                x = ldexp(fx * hs, 12 - er - dexp[u]);
+            }
             const _Float16 a = (_Float16)(float)x;
             hi[k] = a;
             lo[k] = (_Float16)(float)(x - (double)(float)a);
@@ -90,14 +115,15 @@ __global__ __launch_bounds__(256) void wh_split_h_kernel(const int* __restrict__
     }
 }
 
-// WH[row][col] (fp64) = hscale * 2^-rexp[row] * sum_k (Whi + Wlo)[row][k] (Hhi + Hlo)[col][k]
+// WH[row][col] (fp64) = 2^(dexp[col] - 12 - rexp[row]) * sum_k (Whi + Wlo)[row][k] (Hhi + Hlo)[col][k]
 // WLO: this instantiation serves the 128-row blocks of W whose low pieces are (not) all zero; both are launched and a
 // workgroup of the other kind leaves at once (the flags are only known on the device).
 template <bool WLO>
 __global__ __launch_bounds__(256, 2) void wh_gemm_kernel(const char* __restrict__ Wp, const char* __restrict__ Hp,
                                                         const int* __restrict__ rexp, const int* __restrict__ wlo_any,
-                                                        const double* __restrict__ hscale, double* __restrict__ WH, int m, int n,
-                                                        int KT, int tiles_m, int tiles_n) {
+                                                        const int* __restrict__ dexp, const float* __restrict__ W,
+                                                        const double* __restrict__ hdiag64, double* __restrict__ WH, int m,
+                                                        int n, int KT, int tiles_m, int tiles_n) {
     __shared__ __align__(16) char lds[2][4 * WIMG];  // per buffer: Whi, Wlo, Hhi, Hlo images
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
@@ -146,12 +172,27 @@ __global__ __launch_bounds__(256, 2) void wh_gemm_kernel(const char* __restrict_
     for (int ks = 0; ks < 2; ++ks) coff[ks] = ((ks * 2 + hf) ^ swz) << 4;
 
     f16v acc[2][2];
+    double accd[2][2][16];  // the fp32 accumulators are emptied into these every WFLUSH k tiles
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.0f;
+                accd[i][j][r] = 0.0;
+            }
+    auto flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    accd[i][j][r] += (double)acc[i][j][r];
+                    acc[i][j][r] = 0.0f;
+                }
+    };
 
     gload(0);
     sstore(0);
@@ -187,23 +228,26 @@ __global__ __launch_bounds__(256, 2) void wh_gemm_kernel(const char* __restrict_
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
             }
         }
+        if ((kt & (WFLUSH - 1)) == WFLUSH - 1) flush();
         sstore((kt + 1) & 1);
         __syncthreads();
     }
+    flush();
 
     // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const double hs = *hscale * 65536.0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = tm * WT + wm + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
             if (row >= m) continue;
-            const double rs = hs * ldexp(1.0, -rexp[row]);
+            const int re = -12 - rexp[row];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = tn * WT + wn + 32 * j + l31;
-                if (col < n) WH[(int64_t)row * n + col] = (double)acc[i][j][reg] * rs;
+                if (col < n)
+                    WH[(int64_t)row * n + col] =
+                        ldexp(accd[i][j][reg], re + dexp[col]) + (double)W[(int64_t)row * n + col] * hdiag64[col];
             }
         }
 }
@@ -220,16 +264,18 @@ WhLayout wh_layout(int64_t m, int64_t n) {
     return lo;
 }
 
-int wh_gemm(const float* W, const int* Hint, const double* hscale, int64_t m, int64_t n, const WhLayout& lo, char* wp, char* hp,
-            int* rexp, int* wlo_any, double* WH, hipStream_t stream) {
+int wh_gemm(const float* W, const int* Hint, const short* Jint, const int* ext, const int* dexp, const double* hdiag64,
+            const double* hscale, int64_t m, int64_t n, const WhLayout& lo, char* wp, char* hp, int* rexp, int* wlo_any, double* WH,
+            hipStream_t stream) {
     GANQ_HIP_CHECK(hipMemsetAsync(wlo_any, 0, lo.wlo_bytes, stream));
-    hipLaunchKernelGGL(wh_split_w_kernel, dim3((unsigned)(lo.tiles_m * WT)), dim3(256), 0, stream, W, (int)m, (int)n, (int)lo.KT, wp,
-                       rexp, wlo_any);
-    hipLaunchKernelGGL(wh_split_h_kernel, dim3((unsigned)(lo.tiles_n * WT)), dim3(256), 0, stream, Hint, (int)n, (int)lo.KT, hp);
+    hipLaunchKernelGGL(wh_split_w_kernel, dim3((unsigned)(lo.tiles_m * WT)), dim3(256), 0, stream, W, dexp, (int)m, (int)n,
+                       (int)lo.KT, wp, rexp, wlo_any);
+    hipLaunchKernelGGL(wh_split_h_kernel, dim3((unsigned)(lo.tiles_n * WT)), dim3(256), 0, stream, Hint, Jint, ext, dexp, hscale,
+                       (int)n, (int)lo.KT, hp);
     hipLaunchKernelGGL(wh_gemm_kernel<false>, dim3((unsigned)(lo.tiles_m * lo.tiles_n)), dim3(256), 0, stream, wp, hp, rexp, wlo_any,
-                       hscale, WH, (int)m, (int)n, (int)lo.KT, (int)lo.tiles_m, (int)lo.tiles_n);
+                       dexp, W, hdiag64, WH, (int)m, (int)n, (int)lo.KT, (int)lo.tiles_m, (int)lo.tiles_n);
     hipLaunchKernelGGL(wh_gemm_kernel<true>, dim3((unsigned)(lo.tiles_m * lo.tiles_n)), dim3(256), 0, stream, wp, hp, rexp, wlo_any,
-                       hscale, WH, (int)m, (int)n, (int)lo.KT, (int)lo.tiles_m, (int)lo.tiles_n);
+                       dexp, W, hdiag64, WH, (int)m, (int)n, (int)lo.KT, (int)lo.tiles_m, (int)lo.tiles_n);
     GANQ_LAUNCH_CHECK();
     return 0;
 }

@@ -8,8 +8,8 @@ What shards, and the exchange step each way needs:
     it.  Exchange: the calibration activations (or the finished Hessian) reach every owner by broadcast /
     all-reduce; the owner broadcasts the quantized result back.
   * row level -- rows of W are independent in S-solve, T-update and k-means (algo.md:10), only best-of-K is
-    global: `run_layer_row_sharded` gives rank r a contiguous row slice, all-reduces the K per-iteration
-    distances (K doubles) and all-gathers the rows.
+    global: `run_layer_row_sharded` gives rank r a contiguous row slice, runs the fused loop on it (no collective
+    inside), all-gathers the K x m per-row losses (the decision) and then the chosen rows.
 Layers of a transformer are sequentially dependent (module_looper.py:354-407) and are never run concurrently.
 
 The compute calls go through `solver` (default: the HIP library); tests inject a CPU solver to exercise the
@@ -52,7 +52,6 @@ def init_from_env(backend: Optional[str] = None) -> Dist:
     share = os.environ.get("GANQ_DIST_SHARE_DEVICE", "") == "1"
     if use_cuda:
         torch.cuda.set_device(0 if share else local)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if not td.is_initialized():
@@ -127,31 +126,59 @@ def allreduce_hessian(H: torch.Tensor, dist: Dist) -> torch.Tensor:
 
 
 def share_module_result(processor, named_module, owner: int, dist: Dist):
-    """owner broadcasts (wq, indices, codebook) of a finished module; the other ranks install them"""
+    """owner broadcasts everything `GPTQProcessor.finalize` / `pack` need of a finished module -- the quantized weight,
+    indices, codebook, the compat scale / zero / g_idx and, with the outlier split on, the CSR outliers -- and the
+    other ranks install them, so every rank (the one that saves the checkpoint included) holds identical results."""
     lin = named_module.module
     dev = lin.weight.device
     m, n = named_module.state["out_features"], named_module.state["in_features"]
-    meta = torch.zeros(2, dtype=torch.int64, device=dev)
+    # meta: present, bits, nnz (-1: no outlier split), scale columns, zero columns
+    meta = torch.zeros(5, dtype=torch.int64, device=dev)
     res = processor.results().get(named_module.full_name) if dist.rank == owner else None
-    if dist.rank == owner:
-        meta[0] = 1 if res is not None else 0
-        meta[1] = res["bits"] if res is not None else 0
+    if dist.rank == owner and res is not None:
+        out = res.get("ganq_outliers")
+        meta[0], meta[1] = 1, res["bits"]
+        meta[2] = -1 if out is None else int(out[1].numel())
+        meta[3] = 0 if res.get("scale") is None else res["scale"].reshape(m, -1).shape[1]
+        meta[4] = 0 if res.get("zero") is None else res["zero"].reshape(m, -1).shape[1]
     broadcast_tensor(meta, owner)
     if int(meta[0]) == 0:
         return  # module was skipped by the owner
-    bits = int(meta[1])
-    wq = lin.weight.data if dist.rank == owner else torch.empty_like(lin.weight.data)
-    q = res["ganq_q"] if dist.rank == owner else torch.empty((m, n), dtype=torch.uint8, device=dev)
-    lut = res["ganq_lut"] if dist.rank == owner else torch.empty((m, 2 ** bits), dtype=torch.float32, device=dev)
-    if dist.rank == owner:
-        wq, q, lut = wq.contiguous(), q.contiguous(), lut.contiguous()
-    for t in (wq, q, lut):
+    bits, nnz, sc_cols, ze_cols = int(meta[1]), int(meta[2]), int(meta[3]), int(meta[4])
+    is_owner = dist.rank == owner
+
+    def take(t, shape, dtype):
+        """the owner's tensor (on the device, contiguous) or a receive buffer of the same shape"""
+        if is_owner:
+            return t.to(device=dev, dtype=dtype).reshape(shape).contiguous()
+        return torch.empty(shape, dtype=dtype, device=dev)
+
+    wq = take(lin.weight.data if is_owner else None, tuple(lin.weight.shape), lin.weight.dtype)
+    q = take(res["ganq_q"] if is_owner else None, (m, n), torch.uint8)
+    lut = take(res["ganq_lut"] if is_owner else None, (m, 2 ** bits), torch.float32)
+    g_idx = take(res["g_idx"] if is_owner else None, (n,), torch.int32)
+    payload = [wq, q, lut, g_idx]
+    scale = zero = None
+    if sc_cols:
+        scale = take(res["scale"] if is_owner else None, (m, sc_cols), torch.float32)
+        payload.append(scale)
+    if ze_cols:
+        zero = take(res["zero"] if is_owner else None, (m, ze_cols), torch.float32)
+        payload.append(zero)
+    outliers = None
+    if nnz >= 0:
+        rowptr = take(res["ganq_outliers"][0] if is_owner else None, (m + 1,), torch.int32)
+        cols = take(res["ganq_outliers"][1] if is_owner else None, (nnz,), torch.int32)
+        vals = take(res["ganq_outliers"][2] if is_owner else None, (nnz,), torch.float32)
+        outliers = (rowptr, cols, vals)
+        payload += [rowptr] + ([cols, vals] if nnz else [])
+    for t in payload:
         broadcast_tensor(t, owner)
-    if dist.rank != owner:
+    if not is_owner:
         lin.weight.data = wq
         named_module.state.update({"wq": wq, "ganq_q": q, "ganq_lut": lut})
-        processor.results()[named_module.full_name] = {"scale": None, "zero": None, "g_idx": None, "ganq_q": q,
-                                                       "ganq_lut": lut, "bits": bits}
+        processor.results()[named_module.full_name] = {"scale": scale, "zero": zero, "g_idx": g_idx, "ganq_q": q,
+                                                       "ganq_lut": lut, "bits": bits, "ganq_outliers": outliers}
 
 
 class HipSolver:
@@ -162,57 +189,66 @@ class HipSolver:
 
         self._lib = _lib
 
-    def matmul(self, A, B):
-        return self._lib.matmul_f32(A, B)
+    def run_layer_rows(self, W, H, L, T0, K, alias_q, rcond):
+        """fused K-iteration loop on a row slice -> dict(T_all [K,m,V], loss_rows_all [K,m], Q_last, Q_all or None)"""
+        return self._lib.run_layer_rows(W, H, L, T0, K, alias_q=alias_q, rcond=rcond)
 
-    def solve_s(self, W, L, T):
-        return self._lib.solve_s(W, L, T)
+    def select_best(self, loss_rows_all):
+        """[K, m] per-row losses of the whole layer -> (dists [K], best_k) in the single-GPU loop's summation order"""
+        return self._lib.select_best(loss_rows_all)
 
-    def update_t(self, WH, H, Q, V, rcond):
-        return self._lib.update_t(WH, H, Q, V, rcond)
 
-    def quad_loss(self, W, H, T, Q):
-        return self._lib.quad_loss(W, H, T, Q)
+def allgather_rows(local: torch.Tensor, slices: List[Tuple[int, int]], dim: int, dist: Dist) -> torch.Tensor:
+    """concatenate every rank's rows (ragged slices) along `dim`: ONE all-gather of equal-sized padded blocks"""
+    if dist.world == 1:
+        return local
+    pad = max(b - a for a, b in slices)
+    shape = list(local.shape)
+    shape[dim] = pad
+    block = torch.zeros(shape, dtype=local.dtype, device=local.device)
+    if local.shape[dim]:
+        block.narrow(dim, 0, local.shape[dim]).copy_(local)
+    if td.get_backend() == "gloo" and block.is_cuda:
+        parts = [torch.empty(shape, dtype=local.dtype) for _ in range(dist.world)]
+        td.all_gather(parts, block.cpu())
+        parts = [p.to(local.device) for p in parts]
+    else:
+        parts = [torch.empty_like(block) for _ in range(dist.world)]
+        td.all_gather(parts, block)
+    return torch.cat([parts[r].narrow(dim, 0, b - a) for r, (a, b) in enumerate(slices)], dim=dim)
 
 
 def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: float = -1.0, dist: Optional[Dist] = None,
                           solver=None):
     """ganq.py:516-634 with the rows of W split over the ranks.  Every rank passes the FULL W / T0 (replicated) and
-    gets the FULL (T_best, Q, dists, best_k) back.  Exchange: one all-reduce of K doubles, one all-gather of rows."""
+    gets the FULL (T_best, Q, dists, best_k) back.
+
+    Each rank runs the FUSED loop (ganq_run_layer_rows: incremental bucket sums, closed-form loss, packed L -- the same
+    kernels as the single-GPU path) on its row slice with no collective inside; afterwards ONE all-gather of the K x m
+    per-row losses lets every rank form the K distances in the single-GPU summation order (ganq_select_best), so the
+    best-of-K decision (ganq.py:621-626) and every returned bit equal the unsharded run's; then one all-gather of the
+    chosen codebook rows and one of the index rows."""
     dist = dist or Dist.current()
     solver = solver or HipSolver()
     m, n = W.shape
     V = T0.shape[1]
-    lo, hi = row_slices(m, dist.world)[dist.rank]
-    Wl, T = W[lo:hi].contiguous(), T0[lo:hi].contiguous()
-    WH = solver.matmul(Wl, H) if hi > lo else Wl
-    Ts, Qs, ds = [], [], []
-    for _ in range(K):
-        if hi > lo:
-            Q = solver.solve_s(Wl, L, T)
-            T = solver.update_t(WH, H, Q, V, rcond)
-            d = solver.quad_loss(Wl, H, T, Q).reshape(1).to(torch.float64)
-        else:
-            Q = torch.empty((0, n), dtype=torch.uint8, device=W.device)
-            d = torch.zeros(1, dtype=torch.float64, device=W.device)
-        Ts.append(T)
-        Qs.append(Q)
-        ds.append(d)
-    dists = torch.cat(ds)
-    if dist.world > 1:
-        allreduce_sum(dists)  # best-of-K is global over rows (ganq.py:622-626)
-    best_k = int(torch.argmin(dists))  # first minimum == the reference's strict `<` scan
-    T_loc = Ts[best_k]
-    Q_loc = Qs[K - 1] if alias_q else Qs[best_k]
-    if dist.world == 1:
-        return T_loc, Q_loc, dists, best_k
-    T_full = torch.empty((m, V), dtype=T0.dtype, device=W.device)
-    Q_full = torch.empty((m, n), dtype=torch.uint8, device=W.device)
-    for r, (a, b) in enumerate(row_slices(m, dist.world)):  # ragged slices: one broadcast per owner
-        if b > a:
-            tt = T_loc if r == dist.rank else torch.empty((b - a, V), dtype=T0.dtype, device=W.device)
-            qq = Q_loc if r == dist.rank else torch.empty((b - a, n), dtype=torch.uint8, device=W.device)
-            broadcast_tensor(tt, r)
-            broadcast_tensor(qq, r)
-            T_full[a:b], Q_full[a:b] = tt, qq
+    # 128-row alignment keeps the per-128-row decisions of the W @ H kernel identical to the unsharded run
+    slices = row_slices(m, dist.world, align=128 if m >= 128 * dist.world else 16)
+    lo, hi = slices[dist.rank]
+    if hi > lo:
+        rec = solver.run_layer_rows(W[lo:hi].contiguous(), H, L, T0[lo:hi].contiguous(), K, alias_q, rcond)
+        loss_loc, T_all, Q_last, Q_all = rec["loss_rows_all"], rec["T_all"], rec["Q_last"], rec["Q_all"]
+    else:
+        loss_loc = torch.zeros((K, 0), dtype=torch.float64, device=W.device)
+        T_all = torch.zeros((K, 0, V), dtype=T0.dtype, device=W.device)
+        Q_last = torch.zeros((0, n), dtype=torch.uint8, device=W.device)
+        Q_all = None if alias_q else torch.zeros((K, 0, n), dtype=torch.uint8, device=W.device)
+    loss_all = allgather_rows(loss_loc, slices, 1, dist)  # K x m doubles: the only exchange the decision needs
+    dists, best_k_t = solver.select_best(loss_all)
+    best_k = int(best_k_t)
+    kk = best_k if best_k >= 0 else K - 1  # no iteration won (all NaN): the last codebook, like the single-GPU loop
+    T_loc = T_all[kk]
+    Q_loc = Q_last if (alias_q or best_k < 0) else Q_all[kk]
+    T_full = allgather_rows(T_loc.contiguous(), slices, 0, dist)
+    Q_full = allgather_rows(Q_loc.contiguous(), slices, 0, dist)
     return T_full, Q_full, dists, best_k

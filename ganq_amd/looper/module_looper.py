@@ -110,8 +110,10 @@ class ModuleLooper:
                     if self.processor.is_skipped(named[n]):
                         continue
                     task = self.processor.tasks[n]
+                    # a follower takes the leader's Hessian AND prologue: only when every setting the prologue depends on
+                    # is the same (a `dynamic` override of damp_percent / act_sort for one module makes it its own leader)
                     if (self.share_group_hessian and leader is not None
-                            and self.processor.tasks[leader].columns == task.columns):
+                            and self.processor.tasks[leader]._prologue_key() == task._prologue_key()):
                         task.follow(self.processor.tasks[leader])
                         continue
                     if leader is None:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GANQ_HIP_ABI_VERSION 1
+#define GANQ_HIP_ABI_VERSION 2
 
 /* flags for ganq_run_layer */
 #define GANQ_FLAG_ALIAS_Q 1u /* reference torch-branch behaviour: indices of the LAST iteration are returned with \
@@ -50,7 +50,7 @@ int ganq_debug_div_check(uint64_t count, uint32_t seed, unsigned long long* mism
                          void* stream);
 
 /* Developer check (tests): WH_out [m,n] fp64 = the W @ H_fixed product the fused driver feeds to the T-update (fp16 matrix
- * cores, operands split into two fp16 pieces; GANQ_WH_F64=1: the fp64 GEMM), Hfixed_out [n,n] fp64 (may be NULL) = the
+ * cores, operands split into two fp16 pieces; option GANQ_WH_F64=1: the fp64 GEMM), Hfixed_out [n,n] fp64 (may be NULL) = the
  * 31-bit fixed-point H it is formed with.  Allocates its own scratch and synchronises the stream. */
 int ganq_debug_wh_product(const float* W, const float* H, int64_t m, int64_t n, double* WH_out, double* Hfixed_out, void* stream);
 
@@ -113,6 +113,22 @@ int ganq_run_layer(const float* W, const float* H, const float* L, int64_t ldl, 
                    int64_t n, int V, int K, uint32_t flags, double rcond, float* T_best, uint8_t* Q_out,
                    double* dists, int32_t* best_k, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- e: the same fused loop on a SLICE of a layer's rows, for a layer whose rows are sharded over several GPUs
+ * (rows are independent in every stage of ganq.py:525-634; only the best-of-K decision :621-626 sums over all rows).
+ * Same arguments as ganq_run_layer for the slice's m rows, plus optional per-iteration records (device, may be NULL):
+ *   T_all [K,m,V] fp32 codebook after each iteration, loss_rows_all [K,m] fp64 per-row loss of each iteration,
+ *   Q_all [K,m,n] uint8 indices of each iteration (only needed without GANQ_FLAG_ALIAS_Q).
+ * T_best / Q_out / dists / best_k describe the slice alone.  The owner of the layer gathers loss_rows_all of every
+ * slice in row order and calls ganq_select_best, which forms the distances in the single-call loop's own summation
+ * order: a sharded layer takes bit-for-bit the decision of the unsharded one.  No collective is needed inside the loop. */
+int ganq_run_layer_rows(const float* W, const float* H, const float* L, int64_t ldl, const float* T0, int64_t m,
+                        int64_t n, int V, int K, uint32_t flags, double rcond, float* T_best, uint8_t* Q_out,
+                        double* dists, int32_t* best_k, float* T_all, double* loss_rows_all, uint8_t* Q_all,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* loss_rows_all [K,m] (all rows of the layer, row order) -> dists [K] fp64, best_k int32 (device): first k with the
+ * smallest distance, strict <, NaN never wins (ganq.py:625); -1 if no iteration wins. */
+int ganq_select_best(const double* loss_rows_all, int64_t m, int K, double* dists, int32_t* best_k, void* stream);
+
 /* ---- a9: LUT-dequant linear forward (replaces FakeQuantLinear.forward, fake.py:88-89) -------
  * y[M,m] = x[M,n] @ dequant(qweight, lut)^T + bias.   dtype: 0 = fp16, 1 = bf16 (x, lut, bias, y).
  * qweight: indices packed `bits` per index along the in_features dimension in the GPTQ int32
@@ -160,6 +176,15 @@ int ganq_outlier_extract(float* W, int64_t m, int64_t n, const float* cut, const
                          void* stream);
 int ganq_outlier_matmul(const void* x, int dtype, int64_t M, int64_t m, int64_t n, const int32_t* rowptr, const int32_t* cols,
                         const void* vals, float* out, void* stream);
+
+/* ---- developer / test switches.  They are read from the environment (variable == option name) once, when the library
+ * is loaded; afterwards only these calls change them -- the compute entry points never call getenv().  Options:
+ * GANQ_T_FULL, GANQ_T_INCR_THR, GANQ_T_JACOBI, GANQ_SOLVE_ALL_ROWS, GANQ_MUPDATE_LDS, GANQ_WH_F64, GANQ_KMEANS_WCAP,
+ * GANQ_CHOL_LOOKAHEAD, GANQ_ACCUM_DEBUG, GANQ_LUT_INWG, GANQ_LUT_WGS, GANQ_LUT_KS, GANQ_H_EXT, GANQ_SOLVE_VARIANT
+ * (meanings: ganq_amd/csrc/runtime.hip).  None of them changes a result except where a test says so. */
+int ganq_debug_set_option(const char* name, long long value);
+int ganq_debug_get_option(const char* name, long long* value);
+int ganq_debug_reset_option(const char* name);
 
 /* ---- per-kernel device timing (HIP events recorded on the caller's stream around every kernel launch) ----
  * ganq_profile_enable(1) starts collecting, ganq_profile_get() sums what has completed: the caller must have

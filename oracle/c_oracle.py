@@ -150,6 +150,27 @@ def run_layer(W, H, L, T0, K, alias_q=True, rcond=-1.0):
     return T, Q, dists, best_k.value
 
 
+def run_layer_trace(W, H, L, T0, K, rcond=-1.0):
+    """all K iterations of the loop on these rows, every iteration recorded: -> dict(T_all [K,m,V], Q_all [K,m,n],
+    loss_rows_all [K,m] fp64, dists [K] (these rows only), best_k (of these rows only))"""
+    W, H, L, T0 = _f32(W), _f32(H), _f32(L), _f32(T0)
+    m, n = W.shape
+    V = T0.shape[1]
+    T = np.empty((m, V), dtype=np.float32)
+    Q = np.empty((m, n), dtype=np.uint8)
+    dists = np.empty(K, dtype=np.float64)
+    best_k = ctypes.c_int(-1)
+    T_all = np.empty((K, m, V), dtype=np.float32)
+    Q_all = np.empty((K, m, n), dtype=np.uint8)
+    loss_all = np.empty((K, m), dtype=np.float64)
+    rc = lib().ganq_oracle_run_layer_trace(_p(W, _f32p), _p(H, _f32p), _p(L, _f32p), _p(T0, _f32p), _i64(m), _i64(n), V,
+                                           K, 1, ctypes.c_double(rcond), _p(T, _f32p), _p(Q, _u8p), _p(dists, _f64p),
+                                           ctypes.byref(best_k), _p(T_all, _f32p), _p(Q_all, _u8p), _p(loss_all, _f64p))
+    if rc:
+        raise RuntimeError(f"ganq_oracle_run_layer_trace failed rc={rc}")
+    return dict(T_all=T_all, Q_all=Q_all, loss_rows_all=loss_all, dists=dists, best_k=best_k.value)
+
+
 def hessian_accum(H, X_half, nsamples_before, b):
     """H [n,n] fp32 updated in place; X_half [rows,n] np.float16."""
     X = np.ascontiguousarray(X_half, dtype=np.float16)

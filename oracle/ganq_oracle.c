@@ -520,14 +520,17 @@ double ganq_oracle_kmeans_cost(const float* w, const double* weights, int64_t n,
  *
  * Outputs: T_best [m,V], Q_out [m,n], dists [K] (fp64), best_k.
  * ------------------------------------------------------------------------------------------ */
-int ganq_oracle_run_layer(const float* W, const float* H, const float* L, const float* T0, int64_t m, int64_t n,
-                          int V, int K, int alias_q, double rcond, float* T_best, uint8_t* Q_out, double* dists,
-                          int* best_k) {
+/* Optional per-iteration records for sampled-row parity at full size (rows are independent in every stage, the
+ * best-of-K decision is the only global step): T_all [K,m,V], Q_all [K,m,n], loss_rows_all [K,m] -- each may be NULL. */
+int ganq_oracle_run_layer_trace(const float* W, const float* H, const float* L, const float* T0, int64_t m, int64_t n,
+                                int V, int K, int alias_q, double rcond, float* T_best, uint8_t* Q_out, double* dists,
+                                int* best_k, float* T_all, uint8_t* Q_all, double* loss_rows_all) {
     float* WH = (float*)malloc(sizeof(float) * (size_t)m * (size_t)n);
     float* T = (float*)malloc(sizeof(float) * (size_t)m * V);
     float* Tn = (float*)malloc(sizeof(float) * (size_t)m * V);
     uint8_t* Q = (uint8_t*)malloc((size_t)m * (size_t)n);
-    if (!WH || !T || !Tn || !Q) return -2;
+    double* rows = (double*)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    if (!WH || !T || !Tn || !Q || !rows) return -2;
     ganq_oracle_matmul(W, H, m, n, n, WH);
     memcpy(T, T0, sizeof(float) * (size_t)m * V);
     double best = INFINITY;
@@ -539,8 +542,11 @@ int ganq_oracle_run_layer(const float* W, const float* H, const float* L, const 
         if (rc) return rc;
         memcpy(T, Tn, sizeof(float) * (size_t)m * V);
         double d;
-        ganq_oracle_quad_loss(W, H, T, Q, m, n, V, &d, NULL);
+        ganq_oracle_quad_loss(W, H, T, Q, m, n, V, &d, rows);
         dists[k] = d;
+        if (T_all) memcpy(T_all + (size_t)k * m * V, T, sizeof(float) * (size_t)m * V);
+        if (Q_all) memcpy(Q_all + (size_t)k * m * n, Q, (size_t)m * (size_t)n);
+        if (loss_rows_all) memcpy(loss_rows_all + (size_t)k * m, rows, sizeof(double) * (size_t)m);
         if (d < best) {
             best = d;
             *best_k = k;
@@ -554,7 +560,15 @@ int ganq_oracle_run_layer(const float* W, const float* H, const float* L, const 
     free(T);
     free(Tn);
     free(Q);
+    free(rows);
     return 0;
+}
+
+int ganq_oracle_run_layer(const float* W, const float* H, const float* L, const float* T0, int64_t m, int64_t n,
+                          int V, int K, int alias_q, double rcond, float* T_best, uint8_t* Q_out, double* dists,
+                          int* best_k) {
+    return ganq_oracle_run_layer_trace(W, H, L, T0, m, n, V, K, alias_q, rcond, T_best, Q_out, dists, best_k, NULL, NULL,
+                                       NULL);
 }
 
 /* ------------------------------------------------------------------------------------------

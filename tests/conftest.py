@@ -34,3 +34,24 @@ def rel_fro(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = np.linalg.norm(b)
     return float(np.linalg.norm(a - b) / (den if den > 0 else 1.0))
+
+
+@pytest.fixture
+def lib_options():
+    """set developer switches of libganq_hip.so for one test (ganq_debug_set_option); every touched option is reset to its
+    default afterwards.  lib_options(reset=(names...), NAME=value, ...)"""
+    from ganq_amd import _lib
+
+    touched = set()
+
+    def apply(reset=(), **opts):
+        for name in reset:
+            _lib.debug_option(name, None)
+            touched.add(name)
+        for name, value in opts.items():
+            _lib.debug_option(name, value)
+            touched.add(name)
+
+    yield apply
+    for name in touched:
+        _lib.debug_option(name, None)

@@ -102,10 +102,10 @@ def test_kmeans_vs_oracle(hip, oracle, m, n, V, seed):
 
 
 @pytest.mark.parametrize("wcap", [64, 200, 1024])
-def test_kmeans_windowed_kernel_small_windows(hip, oracle, wcap, monkeypatch):
+def test_kmeans_windowed_kernel_small_windows(hip, oracle, wcap, lib_options):
     # the large-n kernel (prefix sums in L2, LDS window per segment of nodes) forced onto small rows with a tiny window:
     # exercises multi-segment levels and nodes wider than the window
-    monkeypatch.setenv("GANQ_KMEANS_WCAP", str(wcap))
+    lib_options(GANQ_KMEANS_WCAP=wcap)
     rng = np.random.default_rng(wcap)
     for m, n, V in [(6, 777, 16), (3, 2048, 8), (300, 130, 4)]:
         W = (0.02 * rng.standard_normal((m, n))).astype(np.float16).astype(np.float32)
@@ -190,6 +190,43 @@ def test_lut_linear_repeat_is_bitwise_stable(hip):
                 outs[key] = y.clone()
             else:
                 assert torch.equal(y, outs[key]), (key, rep)
+
+
+@pytest.mark.parametrize("with_outliers", [False, True])
+def test_lut_linear_one_workspace_serves_alternating_shapes(hip, with_outliers):
+    # M = 48 takes the split-K-through-memory variant (KS = 2).  One persistent workspace serves every layer of a model:
+    # a layer with <= 8192 output features followed by one with more (Llama gate / up_proj, 14336) must not find the
+    # smaller layer's partial tiles where its own ticket counters live (the counters have a fixed region).
+    rng = np.random.default_rng(48)
+    M, bits = 48, 4
+    layers = []
+    for m, n in [(4096, 1024), (14336, 1024), (4096, 1024), (14336, 1024)]:
+        Q = rng.integers(0, 16, size=(m, n), dtype=np.uint8)
+        lut = torch.from_numpy((0.02 * rng.standard_normal((m, 16))).astype(np.float32)).half().cuda()
+        x = torch.from_numpy(rng.standard_normal((M, n)).astype(np.float32)).half().cuda()
+        qw = hip.pack_indices(dev(Q), bits)
+        Wq = torch.gather(lut.float(), 1, torch.from_numpy(Q.astype(np.int64)).cuda())
+        ref = x.double() @ Wq.double().T
+        sparse = None
+        if with_outliers:
+            nnz_rows = torch.arange(0, m, 7, device="cuda")
+            rowptr = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+            cnt = torch.zeros(m, dtype=torch.int32, device="cuda")
+            cnt[nnz_rows] = 1
+            rowptr[1:] = torch.cumsum(cnt, 0)
+            cols = ((nnz_rows * 13) % n).to(torch.int32)
+            vals = torch.full((nnz_rows.numel(),), 0.5, dtype=torch.float16, device="cuda")
+            sparse = (rowptr, cols, vals)
+            ref[:, nnz_rows] += 0.5 * x.double()[:, cols.long()]
+        layers.append((x, qw, lut, sparse, ref))
+    for rep in range(3):
+        for x, qw, lut, sparse, ref in layers:
+            if sparse is None:
+                y = hip.lut_linear(x, qw, lut, None, bits)
+            else:
+                y = hip.lut_linear_outliers(x, qw, lut, None, bits, *sparse)
+            assert torch.isfinite(y).all()
+            assert torch.allclose(y.double(), ref, rtol=2 ** -9, atol=2 ** -9 * float(ref.abs().max()) * 0.05 + 1e-6), (rep, tuple(lut.shape))
 
 
 def test_lut_linear_golden_forward(hip):

@@ -1,0 +1,165 @@
+"""K = 10 parity of the fused loop at every module shape of the BASELINE.json configs, the timed benchmark workload included.
+
+For each shape the GPU runs the WHOLE layer through the C-ABI (ganq_run_layer, and ganq_run_layer_rows for the
+per-iteration records); the CPU oracle runs all K iterations on a SAMPLE of rows (rows are independent in every stage,
+ganq.py:525-634; only the best-of-K decision sums over rows, so the GPU's best_k is applied to the sample).  Checked:
+  * indices of every iteration on the sampled rows: bit-exact, free-running (the oracle follows its own codebooks);
+    a row in which a codebook difference within tolerance turns a near-tie the other way (about one index in 10^7) is
+    reported and from then on checked stage by stage against the oracle fed with the GPU's own inputs;
+  * codebook of every iteration <= 1e-5 relative Frobenius, the returned T_best = codebook of iteration best_k;
+  * per-row loss of every iteration <= 1e-6 relative; dists[k] = sum of the row losses;
+  * ganq_run_layer and ganq_run_layer_rows return the same bits; a 128-row slice run on its own returns the same bits
+    as those rows of the full run (what row sharding over GPUs relies on).
+Shapes: opt-125m 768x768, 3072x768, 768x3072; Llama-3.2-1B 2048x2048, 512x2048, 8192x2048,
+2048x8192; Llama-3-8B 4096x4096, 1024x4096, 14336x4096, 4096x14336 at V = 16, and V = 8 at 4096x4096 / 14336x4096
+(config 5).  Weights and activations are synthetic (no checkpoints on the box): W = 0.02 randn rounded to fp16,
+H = (2/p) X^T X + 1 % damping with per-feature scales 0.1 + rand, L = chol of the reference's diagonally dominant matrix
+(gptq.py:289-291), T0 = the HIP k-means init.
+"""
+import argparse
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro
+
+pytestmark = pytest.mark.gpu
+
+K = 10
+TOL_T = 1e-5      # north_star: codebooks within 1e-5 relative Frobenius
+TOL_LOSS = 1e-6   # per-row / total distances
+
+# (m, n, V, sampled rows)
+SHAPES = [
+    (768, 768, 16, 12), (3072, 768, 16, 12), (768, 3072, 16, 12),
+    (2048, 2048, 16, 12), (512, 2048, 16, 12), (8192, 2048, 16, 12), (2048, 8192, 16, 8),
+    (4096, 4096, 16, 12), (1024, 4096, 16, 12), (14336, 4096, 16, 12), (4096, 14336, 16, 4),
+    (4096, 4096, 8, 12), (14336, 4096, 8, 12),
+]
+
+
+def sample_rows(m, count, seed):
+    rng = np.random.default_rng(seed)
+    fixed = [0, 1, 15, 16, m - 1, m - 16, m // 2]          # tile edges of the 16-row S-solve workgroups
+    extra = rng.choice(m, size=count, replace=False).tolist()
+    rows = sorted(set(fixed + extra))
+    keep = sorted(set(rng.choice(len(rows), size=min(count, len(rows)), replace=False).tolist()))
+    return [rows[i] for i in keep]
+
+
+def make_layer(m, n, V, seed):
+    from ganq_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    W = (0.02 * torch.randn(m, n, device="cuda", generator=g)).half().float()
+    p = 2 * n
+    X = torch.randn(p, n, device="cuda", generator=g) * (0.1 + torch.rand(n, device="cuda", generator=g))
+    H = (2.0 / p) * (X.T @ X)
+    del X
+    H += 0.01 * H.diag().mean() * torch.eye(n, device="cuda")
+    H = 0.5 * (H + H.T)
+    off = (H.abs().sum(1) - 2 * H.diag()).clamp(min=1e-8)
+    Hd = H + torch.diag(off)
+    L = _lib.cholesky(Hd)
+    del Hd
+    cw = (torch.rand(n, device="cuda", generator=g, dtype=torch.float64) + 0.5) ** 4
+    T0 = _lib.kmeans_init(W, cw, V)
+    return W, H, L, T0
+
+
+def check_against_oracle(W, H, L, T0, V, rows, tag):
+    """GPU full layer vs oracle trace on `rows`; returns the GPU outputs"""
+    from ganq_amd import _lib
+    from oracle import c_oracle
+
+    m, n = W.shape
+    T_best, Q_last, dists, best_k = _lib.run_layer(W, H, L, T0, K, alias_q=True)
+    rec = _lib.run_layer_rows(W, H, L, T0, K, alias_q=True, want_q_all=True)
+    torch.cuda.synchronize()
+    bk = int(best_k)
+    # the two entry points agree bit for bit, and the records are consistent with the outputs
+    assert torch.equal(rec["T_best"], T_best) and torch.equal(rec["Q_last"], Q_last), tag
+    assert torch.equal(rec["dists"], dists) and int(rec["best_k"]) == bk, tag
+    assert torch.equal(rec["Q_all"][K - 1], Q_last), tag
+    assert torch.equal(rec["T_all"][bk], T_best), tag
+    d = dists.cpu().numpy()
+    assert np.all(np.isfinite(d)) and bk == int(np.argmin(d)) and d[bk] <= d[0], (tag, d)
+    d_sel, bk_sel = _lib.select_best(rec["loss_rows_all"])
+    assert torch.equal(d_sel, dists) and int(bk_sel) == bk, tag
+
+    ridx = torch.tensor(rows, device="cuda")
+    Hn, Ln = H.cpu().numpy(), L.cpu().numpy()
+    Wr, T0r = W[ridx].cpu().numpy(), T0[ridx].cpu().numpy()
+    tr = c_oracle.run_layer_trace(Wr, Hn, Ln, T0r, K)
+    Qg = rec["Q_all"][:, ridx].cpu().numpy()
+    Tg = rec["T_all"][:, ridx].cpu().numpy()
+    lg = rec["loss_rows_all"][:, ridx].cpu().numpy()
+    # Free-running comparison: the oracle follows its OWN codebooks.  A codebook difference within tolerance (1e-7 typical)
+    # can turn a near-tie of the next S-solve the other way (hard part 2) -- about one index in 10^7.  A row
+    # where that happens leaves the free-running comparison (`clean`) and is from then on checked stage by stage against
+    # the oracle fed with the GPU's own inputs (bit-exact indices given the GPU's previous codebook, codebook given the
+    # GPU's indices); at most 2 rows per shape may do so, with at most 2 indices in their first differing iteration.
+    clean = np.ones(len(rows), dtype=bool)
+    first_flips = []
+    WHr = None
+    for k in range(K):
+        differs = np.array([not np.array_equal(Qg[k][i], tr["Q_all"][k][i]) for i in range(len(rows))])
+        newly = differs & clean
+        if newly.any():
+            first_flips += [(k, rows[i], int((Qg[k][i] != tr["Q_all"][k][i]).sum())) for i in np.nonzero(newly)[0]]
+            clean &= ~newly
+        staged = np.nonzero(~clean)[0]
+        if staged.size:
+            Tprev = T0r[staged] if k == 0 else Tg[k - 1][staged]
+            Qs = c_oracle.solve_s(Wr[staged], Ln, Tprev)
+            assert np.array_equal(Qs, Qg[k][staged]), f"{tag}: iteration {k}: indices differ from the oracle given the GPU's own codebook"
+            if WHr is None:
+                WHr = c_oracle.matmul(Wr, Hn)
+            Ts = c_oracle.update_t(WHr[staged], Hn, Qg[k][staged], V)
+            assert rel_fro(Tg[k][staged], Ts) < TOL_T, f"{tag}: iteration {k}: staged codebook check"
+        c = np.nonzero(clean)[0]
+        e = rel_fro(Tg[k][c], tr["T_all"][k][c])
+        assert e < TOL_T, f"{tag}: codebook of iteration {k} rel. Frobenius {e:.3e}"
+        el = np.abs(lg[k][c] - tr["loss_rows_all"][k][c]).max() / np.abs(tr["loss_rows_all"][k][c]).max()
+        assert el < TOL_LOSS, f"{tag}: per-row loss of iteration {k} differs by {el:.3e}"
+    assert len(first_flips) <= 2 and all(cnt <= 2 for _, _, cnt in first_flips), f"{tag}: near-tie flips (iteration, row, indices): {first_flips}"
+    if first_flips:
+        print(f"[{tag}] near-tie flips vs the free-running oracle (iteration, row, indices): {first_flips}")
+    c = np.nonzero(clean)[0]
+    assert rel_fro(T_best[ridx].cpu().numpy()[c], tr["T_all"][bk][c]) < TOL_T, tag
+    return T_best, Q_last, dists, bk, rec
+
+
+@pytest.mark.parametrize("m,n,V,nrows", SHAPES, ids=[f"{m}x{n}_V{V}" for m, n, V, _ in SHAPES])
+def test_config_shape_k10_vs_oracle(m, n, V, nrows):
+    from ganq_amd import _lib
+
+    _lib.selftest()
+    W, H, L, T0 = make_layer(m, n, V, seed=m * 7 + n + V)
+    rows = sample_rows(m, nrows, seed=n + V)
+    T_best, Q_last, dists, bk, rec = check_against_oracle(W, H, L, T0, V, rows, f"{m}x{n} V={V}")
+    # a slice of rows run on its own (what one rank of a row-sharded layer does) gives the bits of the full run
+    lo = (m // 2) // 128 * 128
+    hi = min(m, lo + 128)
+    sl = _lib.run_layer_rows(W[lo:hi].contiguous(), H, L, T0[lo:hi].contiguous(), K, alias_q=True, want_q_all=False)
+    assert torch.equal(sl["T_all"], rec["T_all"][:, lo:hi]), "codebooks of a row slice differ from the full run"
+    assert torch.equal(sl["Q_last"], Q_last[lo:hi])
+    assert torch.equal(sl["loss_rows_all"], rec["loss_rows_all"][:, lo:hi])
+
+
+def test_bench_workload_k10_vs_oracle():
+    """the exact layer bench.py times (its build_workload: seeds, 128 x 2048 fp16 calibration tokens through the HIP
+    Hessian kernel, the prologue, the HIP k-means init): the timed result is a checked result"""
+    import bench
+    from ganq_amd import distributed as gdist
+
+    args = argparse.Namespace(m=4096, n=4096, bits=4, iters=K, nseq=128, seqlen=2048)
+    dist = types.SimpleNamespace(rank=0, world=1, device=torch.device("cuda:0"))
+    assert gdist is not None
+    cap, setup = bench.build_workload(args, dist, dist.device)
+    rows = sample_rows(4096, 12, seed=2024)
+    T_best, Q_last, dists, bk, rec = check_against_oracle(cap["W"], cap["H"], cap["L"], cap["T0"], 16, rows, "bench workload")
+    d = dists.cpu().numpy()
+    assert np.all(np.diff(d) < 0) or bk == int(np.argmin(d))  # printed by bench.py as dists_last_step / best_k

@@ -30,11 +30,15 @@ def _worker(rank, world, port, out_q):
 
     dist = gdist.init_from_env()
     try:
-        W, H, L, T0 = (torch.from_numpy(a).cuda() for a in synth(80, 256, 16, 77, corr=0.2))
-        T, Q, dists, best_k = gdist.run_layer_row_sharded(W, H, L, T0, 3, alias_q=True, dist=dist)
-        T1, Q1, d1, b1 = _lib.run_layer(W, H, L, T0, 3, alias_q=True)
-        ok_rows = bool(torch.equal(Q, Q1)) and best_k == int(b1) and torch.allclose(dists, d1, rtol=1e-9)
-        ok_rows = ok_rows and float((T - T1).norm() / T1.norm()) < 1e-6
+        # row-sharded loop = the fused driver on each rank's slice + one exchange of per-row losses: every returned bit
+        # (codebooks, indices, the K distances, best_k) equals the single-rank ganq_run_layer result
+        ok_rows = True
+        for (m, n, V, K, alias) in [(80, 256, 16, 3, True), (300, 512, 16, 4, True), (300, 512, 8, 4, False)]:
+            W, H, L, T0 = (torch.from_numpy(a).cuda() for a in synth(m, n, V, 77 + m, corr=0.2))
+            T, Q, dists, best_k = gdist.run_layer_row_sharded(W, H, L, T0, K, alias_q=alias, dist=dist)
+            T1, Q1, d1, b1 = _lib.run_layer(W, H, L, T0, K, alias_q=alias)
+            ok_rows = ok_rows and bool(torch.equal(Q, Q1)) and best_k == int(b1) and bool(torch.equal(dists, d1))
+            ok_rows = ok_rows and bool(torch.equal(T, T1))
 
         torch.manual_seed(0)  # same model on both ranks
         layer = nn.ModuleDict({"q_proj": nn.Linear(64, 64, bias=False), "k_proj": nn.Linear(64, 32, bias=False),
@@ -49,14 +53,22 @@ def _worker(rank, world, port, out_q):
                 return x + self.q_proj(x) + torch.cat([self.k_proj(x), self.v_proj(x)], -1)
 
         blk = Blk(layer)
+        model = nn.Module()
+        model.layers = nn.ModuleList([blk])
         g = torch.Generator(device="cuda").manual_seed(5)
         xs = [torch.randn(2, 40, 64, device="cuda", generator=g).half() for _ in range(3)]
-        proc = GPTQProcessor(QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2))
+        # with the outlier split on: the non-owner ranks must receive the owner's exact outliers as well
+        proc = GPTQProcessor(QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2,
+                                            ganq_outlier_ratio=0.05))
         with torch.no_grad():
             ModuleLooper(proc, [blk], [["q_proj", "k_proj", "v_proj"]], layers_prefix="layers").loop(xs)
         owners = gdist.assign({"q_proj": (64, 64), "k_proj": (32, 64), "v_proj": (32, 64)}, world)
         mine = sorted(n for n, r in owners.items() if r == rank)
+        proc.finalize(model)  # nn.Linear -> GanqHipQuantLinear built from the (received) results
         state = {k: v.float().cpu().numpy() for k, v in blk.state_dict().items()}
+        for name in ("q_proj", "k_proj", "v_proj"):
+            state["dequant." + name] = getattr(blk, name).dequantize_weight().float().cpu().numpy()
+            state["nnz." + name] = np.array([int(proc.results()["layers.0." + name]["ganq_outliers"][1].numel())])
         out_q.put((rank, ok_rows, mine, sorted(proc.results()), state))
     except Exception as e:  # report instead of letting the parent wait for its queue timeout
         out_q.put((rank, False, [f"ERROR {type(e).__name__}: {e}"], [], {}))
@@ -81,4 +93,5 @@ def test_two_ranks_share_one_gpu():
     assert mine0 and mine1 and not set(mine0) & set(mine1)          # the group's modules were split over the ranks
     assert names0 == names1 and len(names0) == 3                      # both ranks hold every result afterwards
     for k in st0:
-        assert np.array_equal(st0[k], st1[k]), k                      # and identical quantized weights
+        assert np.array_equal(st0[k], st1[k]), k                      # and identical quantized weights / packed layers
+    assert all(int(st0["nnz." + n][0]) > 0 for n in ("q_proj", "k_proj", "v_proj"))  # the outliers travelled

@@ -246,17 +246,14 @@ def test_run_layer_ten_iterations_vs_oracle(hip, oracle, half_w):
 
 
 @pytest.mark.parametrize("m,n,V,K,seed", [(96, 1024, 16, 6, 41), (40, 777, 8, 5, 42), (33, 250, 4, 4, 43), (64, 4112, 16, 3, 44)])
-def test_run_layer_incremental_equals_full(hip, m, n, V, K, seed, monkeypatch):
+def test_run_layer_incremental_equals_full(hip, m, n, V, K, seed, lib_options):
     # the loop keeps the integer bucket sums between iterations and only moves the entries of changed indices;
     # that must be bit-identical to re-accumulating everything, also through the device-side fallback
     W, H, L, T0 = synth(m, n, V, seed, corr=0.2)
     args = (dev(W), dev(H), dev(L), dev(T0), K)
     ref = None
-    for env in ({"GANQ_T_FULL": "1"}, {}, {"GANQ_T_INCR_THR": "0"}, {"GANQ_T_INCR_THR": str(m * n // 400)}):
-        for k in ("GANQ_T_FULL", "GANQ_T_INCR_THR"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for env in ({"GANQ_T_FULL": 1}, {}, {"GANQ_T_INCR_THR": 0}, {"GANQ_T_INCR_THR": m * n // 400}):
+        lib_options(reset=("GANQ_T_FULL", "GANQ_T_INCR_THR"), **env)
         T, Q, d, bk = hip.run_layer(*args, alias_q=False)
         out = (T.clone(), Q.clone(), d.clone(), int(bk))
         if ref is None:
@@ -266,7 +263,7 @@ def test_run_layer_incremental_equals_full(hip, m, n, V, K, seed, monkeypatch):
             assert out[3] == ref[3]
 
 
-def test_run_layer_incremental_many_changes(hip, monkeypatch):
+def test_run_layer_incremental_many_changes(hip, lib_options):
     # a poor initial codebook makes a large share of the indices change in the first update: more than 32 per pass and
     # more than the 512 per row the matrix-core kernel caches in LDS; never falling back must equal always re-accumulating
     m, n, V, K = 24, 2048, 16, 3
@@ -279,11 +276,8 @@ def test_run_layer_incremental_many_changes(hip, monkeypatch):
     per_row = (q_first != q_second).sum(dim=1)
     assert int(per_row.max()) > 512 and int(per_row.min()) > 32, per_row
     outs = []
-    for env in ({"GANQ_T_FULL": "1"}, {"GANQ_T_INCR_THR": str(m * n)}, {"GANQ_T_INCR_THR": str(m * n), "GANQ_MUPDATE_LDS": "1"}):
-        for k in ("GANQ_T_FULL", "GANQ_T_INCR_THR"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for env in ({"GANQ_T_FULL": 1}, {"GANQ_T_INCR_THR": m * n}, {"GANQ_T_INCR_THR": m * n, "GANQ_MUPDATE_LDS": 1}):
+        lib_options(reset=("GANQ_T_FULL", "GANQ_T_INCR_THR", "GANQ_MUPDATE_LDS"), **env)
         T, Q, d, bk = hip.run_layer(*args, alias_q=False)
         outs.append((T.clone(), Q.clone(), d.clone(), int(bk)))
     for o in outs[1:]:
@@ -291,7 +285,7 @@ def test_run_layer_incremental_many_changes(hip, monkeypatch):
 
 
 @pytest.mark.parametrize("m,n,V", [(256, 1024, 16), (64, 512, 8), (37, 300, 4)])
-def test_update_t_cholesky_path_equals_jacobi_path(hip, oracle, m, n, V, monkeypatch):
+def test_update_t_cholesky_path_equals_jacobi_path(hip, oracle, m, n, V, lib_options):
     # rows whose A is provably above the gelsd cut-off are solved by Cholesky; forcing the eigen-solve for every row
     # must give the same codebook (both solve the same fp32-rounded system in fp64)
     W, H, L, T0 = synth(m, n, V, seed=m + V, corr=0.3)
@@ -299,10 +293,10 @@ def test_update_t_cholesky_path_equals_jacobi_path(hip, oracle, m, n, V, monkeyp
     Q[3, :] = Q[3, :] % (V - 1)  # one row with an unused code: singular A, takes the eigen-solve in both runs
     WH = oracle.matmul(W, H)
     outs = []
-    for jac in ("0", "1"):
-        monkeypatch.setenv("GANQ_T_JACOBI", jac)
+    for jac in (0, 1):
+        lib_options(GANQ_T_JACOBI=jac)
         outs.append(hip.update_t(dev(WH), dev(H), dev(Q.astype(np.uint8)), V).cpu().numpy())
-    monkeypatch.delenv("GANQ_T_JACOBI")
+    lib_options(reset=("GANQ_T_JACOBI",))
     assert rel_fro(outs[0], outs[1]) < 1e-9
     assert (outs[0] == outs[1]).mean() > 0.98  # identical floats but for a rare last-bit rounding of the fp64 result
     To = oracle.update_t(WH, H, Q, V)

@@ -88,24 +88,26 @@ def test_assign_and_row_slices():
 
 
 class OracleSolver:
-    """CPU stand-in for HipSolver, for the gloo tests only"""
+    """CPU stand-in for HipSolver (same two methods), for the gloo tests only: the collective logic of
+    run_layer_row_sharded is exercised with the oracle serving the per-slice loop"""
 
     def __init__(self):
         from oracle import c_oracle
 
         self.o = c_oracle
 
-    def matmul(self, A, B):
-        return torch.from_numpy(self.o.matmul(A.numpy(), B.numpy()))
+    def run_layer_rows(self, W, H, L, T0, K, alias_q, rcond):
+        tr = self.o.run_layer_trace(W.numpy(), H.numpy(), L.numpy(), T0.numpy(), K, rcond)
+        return dict(T_all=torch.from_numpy(tr["T_all"]), loss_rows_all=torch.from_numpy(tr["loss_rows_all"]),
+                    Q_last=torch.from_numpy(tr["Q_all"][K - 1].copy()), Q_all=None if alias_q else torch.from_numpy(tr["Q_all"]))
 
-    def solve_s(self, W, L, T):
-        return torch.from_numpy(self.o.solve_s(W.numpy(), L.numpy(), T.numpy()))
-
-    def update_t(self, WH, H, Q, V, rcond):
-        return torch.from_numpy(self.o.update_t(WH.numpy(), H.numpy(), Q.numpy(), V, rcond))
-
-    def quad_loss(self, W, H, T, Q):
-        return torch.tensor(self.o.quad_loss(W.numpy(), H.numpy(), T.numpy(), Q.numpy()), dtype=torch.float64)
+    def select_best(self, loss_rows_all):
+        d = loss_rows_all.sum(dim=1)  # the HIP library sums in its own fixed order; any fixed order serves the CPU test
+        best, bk = float("inf"), -1
+        for k in range(d.shape[0]):  # ganq.py:625: strict <, first minimum
+            if float(d[k]) < best:
+                best, bk = float(d[k]), k
+        return d, torch.tensor(bk, dtype=torch.int32)
 
 
 def _golden(name):

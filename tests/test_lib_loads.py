@@ -27,7 +27,7 @@ def test_library_builds_loads_and_exports_everything():
     handle = _lib.lib()
     for name in declared_symbols():
         assert hasattr(handle, name), name
-    assert handle.ganq_hip_version() == 1
+    assert handle.ganq_hip_version() == 2
     # size queries are pure host functions
     assert handle.ganq_solve_s_workspace_bytes(4096, 4096, 16) == 2 * 4096 * 4096 * 4  # Err scratch + packed L
     assert handle.ganq_run_layer_workspace_bytes(4096, 4096, 16) > handle.ganq_update_t_workspace_bytes(4096, 4096, 16)
