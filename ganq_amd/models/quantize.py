@@ -60,11 +60,13 @@ def capture_layer_inputs(model: nn.Module, layers: Sequence[nn.Module], batches:
 
 @torch.no_grad()
 def quantize_model(model: nn.Module, calibration: Sequence[torch.Tensor], qcfg: QuantizeConfig,
-                   layer_map: Optional[LayerMap] = None, progress=None, **looper_options) -> GPTQProcessor:
+                   layer_map: Optional[LayerMap] = None, progress=None, processor: Optional[GPTQProcessor] = None,
+                   **looper_options) -> GPTQProcessor:
     """Quantize every Linear the layer map names, layer by layer, on the device the model lives on.  `calibration`:
     token-id tensors [b, seq].  Returns the processor (per-module log, results); the model is modified in place
     (GanqHipQuantLinear modules for FORMAT.GANQ_LUT, dequantised nn.Linear weights for FORMAT.FAKE).
-    looper_options: `early_exit=` / `cache_outputs=` of ModuleLooper (both on by default; results do not depend on them)."""
+    looper_options: `early_exit=` / `cache_outputs=` / `share_group_hessian=` of ModuleLooper (results do not depend on
+    them).  processor: a GPTQProcessor (subclass) to drive instead of a fresh one -- the reference's LoopProcessor slot."""
     lm = layer_map or layer_map_for(model)
     layers = _get_module(model, lm.layers_node)
     dev = next(model.parameters()).device
@@ -72,14 +74,14 @@ def quantize_model(model: nn.Module, calibration: Sequence[torch.Tensor], qcfg: 
     was_training = model.training
     model.eval()
     hidden, kwargs_list = capture_layer_inputs(model, layers, batches)
-    proc = GPTQProcessor(qcfg)
+    proc = processor if processor is not None else GPTQProcessor(qcfg)
+    looper_options.setdefault("share_group_hessian", lm.shared_group_inputs)
 
     def fwd(layer, x, kw):
         return layer(x, **kw)
 
-    ModuleLooper(proc, layers, lm.layer_modules, layers_prefix=lm.layers_node,
-                 share_group_hessian=lm.shared_group_inputs, **looper_options).loop(hidden, kwargs_list, forward=fwd,
-                                                                                                    progress=progress)
+    ModuleLooper(proc, layers, lm.layer_modules, layers_prefix=lm.layers_node, **looper_options).loop(
+        hidden, kwargs_list, forward=fwd, progress=progress)
     proc.finalize(model)
     model.quantize_config = qcfg
     model.train(was_training)

@@ -1,0 +1,123 @@
+"""TEST INFRASTRUCTURE: the reference's quantizer object restated on the CPU, for model-boundary parity tests.
+
+`OracleGANQ` has the surface the looper / processor use of `ganq_amd.quantization.GANQ` (add_batch, quantize() -> 7-tuple,
+free, fwd_counter, nsamples, columns, ganq_indices, ganq_codebook) but computes everything on the host with the CPU
+oracle and the reference's own op sequence:
+  Hessian      gptq.py:96-131     torch CPU (fp32 matmul of the scaled activations, as the reference does)
+  prologue     gptq.py:259-319    torch CPU / LAPACK: dead columns, act_sort, ganq-style L, damping, cholesky ->
+                                  cholesky_inverse -> cholesky(upper)
+  codebook     ganq.py:423-438    oracle k-means with weights diag(Hinv)^-4
+  loop         ganq.py:516-634    oracle/ganq_oracle.c (ganq_oracle_run_layer)
+  outputs      ganq.py:633-646, gptq.py:324-375
+`OracleProcessor` is the product's GPTQProcessor with this quantizer in the GANQ slot.  Nothing under ganq_amd/ imports
+this file.
+"""
+import copy
+import time
+
+import numpy as np
+import torch
+
+from ganq_amd.looper.gptq_processor import GPTQProcessor
+from ganq_amd.quantization.quantizer import Quantizer
+from oracle import c_oracle
+
+
+class OracleGANQ:
+    def __init__(self, module, qcfg):
+        self.module = module.module
+        self.qcfg = qcfg
+        self.device = self.module.weight.device
+        self.W = self.module.weight.data.detach().float().cpu().clone()
+        self.rows, self.columns = self.W.shape
+        self.nsamples = 0
+        self.fwd_counter = 0
+        self.H = torch.zeros((self.columns, self.columns), dtype=torch.float32)
+        self.quantizer = Quantizer(qcfg=qcfg, name=module.name)
+        self.iterations = qcfg.ganq_iterations
+        self.ganq_indices = self.ganq_codebook = self.ganq_outliers = None
+
+    # gptq.py:88-131
+    def add_batch(self, inp, out):
+        self.fwd_counter += 1
+        x = inp.detach().to("cpu")
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        batch = x.shape[0]
+        x = x.reshape(-1, x.shape[-1]).t()
+        self.H *= self.nsamples / (self.nsamples + batch)
+        self.nsamples += batch
+        x = (2.0 / self.nsamples) ** 0.5 * x.float()
+        self.H += x.matmul(x.t())
+
+    def _prologue_key(self):
+        return id(self)  # never shares a prologue
+
+    def follow(self, leader):
+        raise RuntimeError("OracleGANQ: run the looper with share_group_hessian=False")
+
+    @torch.no_grad()
+    def quantize(self, blocksize=128):
+        start = time.time()
+        c = self.qcfg
+        W, H = self.W, self.H
+        self.quantizer.find_params(W, weight=True)
+        dead = torch.diag(H) == 0
+        H[dead, dead] = 1
+        if c.dead == "zero":
+            W[:, dead] = 0
+        else:
+            W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
+        perm = invperm = None
+        if c.act_sort != "none":
+            perm = torch.argsort(torch.diag(H), descending=c.act_sort == "desc")
+            W = W[:, perm].contiguous()
+            H = H[perm][:, perm].contiguous()
+            invperm = torch.argsort(perm)
+        L = None
+        if c.l_damp_style == "ganq":
+            offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
+            L = torch.linalg.cholesky(H + torch.diag(offset))
+        damp_percent = c.damp_percent
+        damp = damp_percent * torch.mean(torch.diag(H))
+        diag = torch.arange(self.columns)
+        H[diag, diag] += damp
+        Xxt_damped = H.clone()
+        Lg = torch.linalg.cholesky(H)
+        if c.l_damp_style == "gptq":
+            L = Lg.clone()
+        Hinv = torch.linalg.cholesky(torch.cholesky_inverse(Lg), upper=True)
+        hd = torch.diagonal(Hinv)
+        V = 2 ** c.bits
+        weights = (hd ** (-4)).double().numpy()
+        Wn = W.numpy()
+        T0 = c_oracle.kmeans_init(Wn, weights, V)
+        alias = bool(getattr(c, "ganq_reference_q_alias", True))
+        T, Q, dists, best_k = c_oracle.run_layer(Wn, Xxt_damped.numpy(), L.numpy(), T0, self.iterations, alias_q=alias)
+        Wq, Losses = c_oracle.dequant_losses(Wn, T, Q, hd.numpy())
+        avg_loss = float(Losses.astype(np.float64).sum()) / self.nsamples
+        group_size = c.group_size if c.group_size != -1 else self.columns
+        g_idx = (torch.arange(self.columns) // group_size).to(torch.int32)
+        Wq_t, Q_t = torch.from_numpy(Wq), torch.from_numpy(Q)
+        if c.desc_act and invperm is not None:
+            Wq_t, Q_t, g_idx = Wq_t[:, invperm], Q_t[:, invperm].contiguous(), g_idx[invperm]
+        self.ganq_indices = Q_t.to(self.device)
+        self.ganq_codebook = torch.from_numpy(T).to(self.device)
+        wq = Wq_t.reshape(self.module.weight.shape).type_as(self.module.weight.data).to(self.device)
+        self.quantizer.find_params(W, weight=True)
+        return (wq, self.quantizer.scale, self.quantizer.zero, g_idx.to(self.device), time.time() - start, avg_loss,
+                damp_percent)
+
+    def free(self):
+        self.W = self.H = None
+
+
+class OracleProcessor(GPTQProcessor):
+    """GPTQProcessor with the CPU oracle in the quantizer slot (gptq_processor.py:86-87)"""
+
+    def preprocess(self, module, buffered_fwd=False):
+        if self.qcfg.dynamic_get(layer_name=module.full_name) is False:
+            return
+        tmp = OracleGANQ(module, copy.deepcopy(self.qcfg))
+        tmp.quantizer.configure(perchannel=True)
+        self.tasks[module.name] = tmp

@@ -129,3 +129,72 @@ def test_quantize_model_save_load_ppl(kind, outlier_ratio, tmp_path):
     packed = sum(p.numel() * p.element_size() for n, p in fresh.state_dict().items() if ".qweight" in n or ".lut" in n)
     dense = sum(mod.in_features * mod.out_features * 2 for mod in fresh.modules() if isinstance(mod, GanqHipQuantLinear))
     assert packed < 0.5 * dense
+
+
+@torch.no_grad()
+def test_opt125m_architecture_hip_vs_cpu_oracle_at_model_boundary():
+    """BASELINE configs[1] as far as the box allows (no checkpoints, no datasets): the opt-125m ARCHITECTURE at its real
+    dimensions (hidden 768, ffn 3072, 12 heads, vocabulary 50272; 2 decoder layers, random initialisation), 4-bit GANQ
+    with the example's settings (basic_usage_wikitext2.py:126-141), quantized twice through the same looper: once by the
+    HIP path, once by the CPU oracle in the quantizer slot (tests/oracle_quantizer.py: the reference's op sequence on
+    the host).  The two quantized models must agree in their logits and in the GPTQ-style perplexity to the metric's
+    tolerance: +-0.05 at the reference's 28.45, i.e. 0.18 % relative."""
+    import copy
+
+    import transformers
+
+    from ganq_amd.models import gptq_style_ppl, quantize_model
+    from ganq_amd.quantization import QuantizeConfig
+    from oracle_quantizer import OracleProcessor
+
+    torch.manual_seed(0)
+    cfg = transformers.OPTConfig(vocab_size=50272, hidden_size=768, ffn_dim=3072, num_hidden_layers=2,
+                                 num_attention_heads=12, max_position_embeddings=2048, word_embed_proj_dim=768)
+    base = transformers.OPTForCausalLM(cfg).half().cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    calib = [torch.randint(0, cfg.vocab_size, (2, 256), generator=g) for _ in range(4)]
+    test_ids = torch.randint(0, cfg.vocab_size, (1, 4 * 512), generator=g)
+
+    def qcfg():
+        return QuantizeConfig(bits=4, quant_method="ganq", format="fake", act_sort="asc", l_damp_style="ganq", dead="mean",
+                              damp_percent=0.01, desc_act=True, group_size=128, ganq_iterations=2)
+
+    m_hip, m_cpu = copy.deepcopy(base), copy.deepcopy(base)
+    p_hip = quantize_model(m_hip, calib, qcfg())
+    p_cpu = quantize_model(m_cpu, calib, qcfg(), processor=OracleProcessor(qcfg()), share_group_hessian=False)
+    assert sorted(p_hip.results()) == sorted(p_cpu.results()) and len(p_hip.results()) == 12
+    # Per module: how many indices differ.  The first group (layer 0 q/k/v) sees identical inputs in both runs and must
+    # agree index for index up to a stray near-tie.  From then on every module is calibrated on the outputs of the modules quantized before it,
+    # so the two runs no longer see the same Hessians: codebooks that agree to 1e-4 upstream change activations by 1e-4,
+    # which moves near-ties -- differences grow with depth (measured: 0.3 % .. 8 % of the indices in the later modules,
+    # with equal losses).  That is a property of sequential calibration, not of either solver; what has to hold at
+    # the model boundary is that both quantized models are equally good: losses, logits, perplexity.
+    worst = 0.0
+    for name in sorted(p_hip.results()):
+        a, b = p_hip.results()[name], p_cpu.results()[name]
+        frac = float((a["ganq_q"] != b["ganq_q"]).float().mean())
+        tdiff = float((a["ganq_lut"] - b["ganq_lut"]).norm() / b["ganq_lut"].norm())
+        print(f"[opt-125m architecture, HIP vs CPU oracle] {name}: differing indices {frac:.5f}, codebooks rel. Frobenius {tdiff:.3e}")
+        worst = max(worst, frac)
+        if "layers.0.self_attn" in name and not name.endswith("out_proj"):
+            assert frac * a["ganq_q"].numel() <= 4, name  # measured: 0 or 1 of 589 824 (a near-tie of the S-solve)
+    assert worst < 0.15
+    la = [float(r["loss"]) for r in p_hip.log]
+    lb = [float(r["loss"]) for r in p_cpu.log]
+    assert np_close(la, lb, 5e-3)
+    x = test_ids[:, :512].cuda()
+    lo_hip, lo_cpu, lo_base = m_hip(x).logits.float(), m_cpu(x).logits.float(), base(x).logits.float()
+    d_q = float((lo_hip - lo_cpu).norm() / lo_cpu.norm())
+    d_b = float((lo_cpu - lo_base).norm() / lo_base.norm())
+    print(f"[opt-125m architecture] logits: HIP vs oracle {d_q:.3e}; quantized vs fp16 {d_b:.3e}")
+    # two equally good roundings of the same weights: closer to each other than either is to the fp16 model (measured 0.3x)
+    assert d_q < 0.5 * d_b
+    ppl_hip, ppl_cpu = gptq_style_ppl(m_hip, test_ids, seqlen=512), gptq_style_ppl(m_cpu, test_ids, seqlen=512)
+    print(f"[opt-125m architecture] GPTQ-style PPL (random weights, random tokens): HIP {ppl_hip:.3f}  oracle {ppl_cpu:.3f}")
+    assert abs(ppl_hip - ppl_cpu) / ppl_cpu < 0.05 / 28.45
+
+
+def np_close(a, b, rtol):
+    import numpy as np
+
+    return bool(np.allclose(np.asarray(a), np.asarray(b), rtol=rtol))

@@ -99,3 +99,37 @@ def test_lut_linear_oracle(golden):
     if bool(g["desc_act"]) or str(g["act_sort"]) == "none":
         # fp16 F.linear on CPU accumulates in fp32 and rounds once
         assert np.allclose(y.astype(np.float16).astype(np.float32), g["y_fwd"].astype(np.float32), rtol=2e-3, atol=2e-3)
+
+
+def test_oracle_quantizer_object_reproduces_reference_seven_tuple(golden):
+    """tests/oracle_quantizer.py (the CPU quantizer object the model-boundary GPU tests compare the HIP path with) against
+    the reference's own quantize() output: indices exact, weight / avg_loss to rounding"""
+    import torch
+    import torch.nn as nn
+
+    from ganq_amd.looper.named_module import NamedModule
+    from ganq_amd.quantization import QuantizeConfig
+    from oracle_quantizer import OracleGANQ
+
+    g = golden
+    m, n, K = int(g["m"]), int(g["n"]), int(g["K"])
+    lin = nn.Linear(n, m, bias=True).half()
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(g["W"]))
+    qcfg = QuantizeConfig(bits=int(g["bits"]), quant_method="ganq", format="fake", act_sort=str(g["act_sort"]),
+                          l_damp_style=str(g["l_damp_style"]), dead=str(g["dead"]), desc_act=bool(g["desc_act"]),
+                          ganq_iterations=K, group_size=int(g["group_size"]), damp_percent=0.01)
+    q = OracleGANQ(NamedModule(lin, "fc1", "model.layers.0.fc1", 0), qcfg)
+    q.quantizer.configure(perchannel=True)
+    for xb in g["X"]:
+        q.add_batch(torch.from_numpy(xb), None)
+    assert rel_fro(q.H.numpy(), g["H_raw"]) < 1e-6
+    wq, scale, zero, g_idx, _, avg_loss, damp = q.quantize()
+    Qref = g["Q"][K - 1]
+    if bool(g["desc_act"]) and str(g["act_sort"]) != "none":
+        Qref = Qref[:, np.argsort(g["perm"])]
+    assert np.array_equal(q.ganq_indices.numpy(), Qref)
+    diff = wq.float().numpy() - g["Wq"].astype(np.float32)
+    assert np.all(np.abs(diff) <= np.spacing(np.abs(g["Wq"]).astype(np.float16)).astype(np.float32))
+    assert abs(avg_loss - float(g["avg_loss"])) < 1e-5 * float(g["avg_loss"])
+    assert np.array_equal(g_idx.numpy(), g["g_idx"].reshape(-1))
