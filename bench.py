@@ -16,9 +16,16 @@ group that shares one set of calibration activations (like q/k/v): rank 0 genera
 activations and broadcasts them over RCCL/xGMI during setup, every rank accumulates the Hessian with the HIP
 kernel and quantizes its layer (seed = rank).  The broadcast time is reported in `setup`.
 
+`--mode rows` (strong scaling): ONE layer whose rows are split over the ranks (ganq_amd.distributed.run_layer_row_sharded:
+the fused loop on each rank's slice, then one all-gather of the K x m per-row losses for the global best-of-K decision and
+one of the chosen rows); value = steps * 4096 / wall time -- the same layer however many GPUs work on it.
+
 Besides the driver contract the JSON line carries `roofline` (dominant kernel of the timed region, measured live
-with HIP events on the launch stream) and `cpu_baseline` (the torch restatement of the reference's own op
-sequence, oracle/ganq_ref.py, timed on this host on a bounded sample of the same workload).
+with HIP events on the launch stream; `achieved` counts the flops of the rows the launches really solved -- converged
+rows are skipped from the third iteration on), `cpu_baseline` (oracle/ganq_oracle.c on this host's cores on a bounded
+sample of the same workload, the torch restatement of the reference's own op sequence beside it) and `lut_forward`
+(BASELINE configs[2]: the LUT decode kernel against torch fp16 F.linear on the same shapes, device time from HIP-graph
+replays, weights hot in the Infinity Cache and cold from HBM).
 """
 import argparse
 import json
@@ -36,6 +43,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 INT8_MFMA_PEAK_TOPS = 5000.0    # MI355X_MICROARCH.md: i8 MFMA = 2x the bf16 rate per clock, bf16 dense ~2.5 PF
+PMC_FILE = "r02_pmc_traffic.json"   # rocprofv3 --pmc summary of the loop's kernels at HEAD (tools/pmc_collect.sh)
 
 
 def log(*a):
@@ -53,7 +61,8 @@ def build_workload(args, dist, dev):
     from ganq_amd.quantization import GANQ, QuantizeConfig
 
     m, n = args.m, args.n
-    g = torch.Generator(device="cpu").manual_seed(0 + dist.rank)
+    seed_rank = getattr(dist, "seed_rank", dist.rank)
+    g = torch.Generator(device="cpu").manual_seed(0 + seed_rank)
     lin = nn.Linear(n, m, bias=False).half()
     with torch.no_grad():
         lin.weight.copy_((0.02 * torch.randn(m, n, generator=g)).half())
@@ -76,7 +85,7 @@ def build_workload(args, dist, dev):
             out = super()._perform_quantization_loop(W, Hinv, blocksize, perm, invperm)
             return out
 
-    q = CaptureGANQ(NamedModule(lin, "proj", f"model.layers.0.proj{dist.rank}", 0), qcfg)
+    q = CaptureGANQ(NamedModule(lin, "proj", f"model.layers.0.proj{seed_rank}", 0), qcfg)
     q.quantizer.configure(perchannel=True)
 
     gs = torch.Generator(device="cpu").manual_seed(999)
@@ -100,13 +109,13 @@ def build_workload(args, dist, dev):
             torch.cuda.synchronize()
         t_hess += time.perf_counter() - t0
     torch.cuda.synchronize()
-    H_copy, n_copy = q.H.clone(), q.nsamples
+    H_copy, n_copy = q.hessian.clone(), q.nsamples
     t0 = time.perf_counter()
     wq, _, _, _, _, avg_loss, damp = q.quantize()  # full quantize(): prologue + k-means + loop + epilogue
     torch.cuda.synchronize()
     t_full = time.perf_counter() - t0
     # the same call again on the same statistics: the first one pays one-time costs (workspaces, library handles)
-    q2 = GANQ(NamedModule(lin, "proj", f"model.layers.0.proj{dist.rank}", 0), qcfg)
+    q2 = GANQ(NamedModule(lin, "proj", f"model.layers.0.proj{seed_rank}", 0), qcfg)
     q2.quantizer.configure(perchannel=True)
     q2.H, q2.nsamples = H_copy, n_copy
     torch.cuda.synchronize()
@@ -156,6 +165,46 @@ def cpu_baseline(cap, args):
             "measured_s": round(t_c, 3), "torch_op_sequence": torch_seq}
 
 
+class _SameSeed:
+    """a Dist whose `rank` reads 0 where build_workload derives seeds / names from it, so that every rank builds the same
+    layer (row-sharded mode); broadcasts still see the real rank"""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.world = dist.world
+        self.device = dist.device
+        self.rank = dist.rank
+        self.seed_rank = 0
+
+
+def lut_forward_report():
+    """GanqHipQuantLinear decode forward vs torch fp16 F.linear (BASELINE configs[2]) -- tools/bench_lut_decode.py"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_lut_decode as bl
+
+    rows = []
+    for (m, n, M, cold) in [(4096, 4096, 1, False), (4096, 4096, 1, True), (14336, 4096, 1, True), (4096, 14336, 1, True),
+                            (4096, 4096, 16, True)]:
+        rows.append(bl.bench(m, n, 4, M, cold))
+    return {"what": "y = x @ dequant(qweight, lut)^T, 4-bit, fp16 activations; device us per call from HIP-graph replays of 200 calls; "
+                    "cold = a ring of layers larger than the 256 MB Infinity Cache", "peak_GBs": HBM_PEAK_GBS, "shapes": rows}
+
+
+def executed_rows(cap, args):
+    """rows the S-solve launches of one layer really solve: all of them in iterations 0 and 1, afterwards the rows whose
+    indices changed in the previous iteration (run_layer.hip); from one extra untimed run with the indices recorded"""
+    from ganq_amd import _lib
+
+    rec = _lib.run_layer_rows(cap["W"], cap["H"], cap["L"], cap["T0"], args.iters, alias_q=True, want_q_all=True)
+    Qa = rec["Q_all"]
+    m = Qa.shape[1]
+    rows = [m, m]
+    for k in range(2, args.iters):
+        changed = int((Qa[k - 1] != Qa[k - 2]).any(dim=1).sum())
+        rows.append((changed + 15) // 16 * 16 if changed else 0)  # whole 16-row workgroup tiles
+    return rows[:args.iters]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +218,9 @@ def main():
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--cpu-rows", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lut", action="store_true", help="skip the lut_forward object")
+    ap.add_argument("--mode", choices=["layers", "rows"], default="layers",
+                    help="layers: one layer per GPU (weak scaling, the default); rows: one layer, rows split over the GPUs (strong)")
     args = ap.parse_args()
 
     from ganq_amd import _lib
@@ -183,12 +235,19 @@ def main():
     _lib.selftest()
     import torch.distributed as td
 
-    cap, setup = build_workload(args, dist, dev)
+    if args.mode == "rows":
+        cap, setup = build_workload(args, _SameSeed(dist), dev)  # every rank needs the SAME layer
+    else:
+        cap, setup = build_workload(args, dist, dev)
     V = 2 ** args.bits
     ws = _lib.run_layer_workspace(args.m, args.n, V, dev)
 
-    def step():
-        return _lib.run_layer(cap["W"], cap["H"], cap["L"], cap["T0"], args.iters, alias_q=True, workspace=ws)
+    if args.mode == "rows":
+        def step():
+            return gdist.run_layer_row_sharded(cap["W"], cap["H"], cap["L"], cap["T0"], args.iters, alias_q=True, dist=dist)
+    else:
+        def step():
+            return _lib.run_layer(cap["W"], cap["H"], cap["L"], cap["T0"], args.iters, alias_q=True, workspace=ws)
 
     for _ in range(args.warmup):
         step()
@@ -222,16 +281,26 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t)
 
+    exec_rows, exec_frac = None, 1.0
+    if dist.rank == 0 and args.mode == "layers":
+        exec_rows = executed_rows(cap, args)
+        exec_frac = sum(exec_rows) / float(args.m * args.iters)
     if dist.rank == 0:
         m, n, K = args.m, args.n, args.iters
-        value = dist.world * args.steps * n / elapsed
+        value = (dist.world if args.mode == "layers" else 1) * args.steps * n / elapsed
         kern = {k: {"total_ms": round(v[0], 3), "launches": v[1], "avg_ms": round(v[0] / v[1], 4)} for k, v in prof_all.items()}
         dom_ms, dom_cnt = prof[dom_name]  # HIP events over the timed region, on the stream the kernel is launched on
         avg_s = dom_ms / dom_cnt / 1e3
         if dom_name == "solve_s_kernel":
-            work = float(m) * n * (n - 1)  # residual chain: n(n-1)/2 fused multiply-adds per row, fp32 matrix cores
+            # residual chain: n(n-1)/2 fused multiply-adds per SOLVED row on the fp32 matrix cores; converged rows are
+            # skipped from the third iteration on, so the flops are those of the rows the launches really solved
+            m_loc = m if args.mode == "layers" else (m + dist.world - 1) // dist.world
+            work_full = float(m_loc) * n * (n - 1)
+            work = work_full * exec_frac
             roof = {"kernel": dom_name, "bound": "mfma", "achieved": round(work / avg_s / 1e12, 3),
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "peak_dtype": "f32"}
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "peak_dtype": "f32",
+                    "executed_rows_per_iteration": exec_rows, "executed_fraction_of_reference_flops": round(exec_frac, 4),
+                    "achieved_if_all_rows_counted": round(work_full / avg_s / 1e12, 3)}
         elif dom_name == "onehot_accum_kernel":
             # bucket sum of H per row on the int8 matrix cores: one-hot [16 codes] x 4 digit planes, pairs u > v only
             work = 2.0 * 16 * 4 * m * n * (n - 1) / 2
@@ -248,11 +317,10 @@ def main():
         roof["frac"] = round(roof["achieved"] / roof["peak"], 5)
         roof["avg_launch_ms"] = round(dom_ms / dom_cnt, 4)
         # HBM bytes per launch from the PMC counters of a separate rocprofv3 --pmc pass over the same kernels
-        # (profiles/r01_pmc_traffic_v11.json, tools/pmc_collect.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-        # for gfx950)
+        # (profiles/<PMC_FILE>, tools/pmc_collect.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
         roof["traffic"] = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v11.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             for k, v in pmc.items():
                 if k.split("<")[0] == dom_name and (m, n) == (4096, 4096):
                     roof["traffic"] = int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
@@ -265,10 +333,12 @@ def main():
             "metric": "weight-columns quantized/sec @4096x4096 (GANQ 4-bit, K=10 alternating-optimisation loop)",
             "value": round(value, 2), "unit": "columns/s", "n_gpus": dist.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if args.mode == "layers" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {m}x{n} layer, {args.bits}-bit (V={V}), K={K}, act_sort=asc, "
-                                   f"l_damp_style=ganq, {args.nseq}x{args.seqlen} fp16 calibration tokens; one layer per GPU",
-                       "m": m, "n": n, "bits": args.bits, "ganq_iterations": K, "parallelism": f"layers x{dist.world}"},
+                                   f"l_damp_style=ganq, {args.nseq}x{args.seqlen} fp16 calibration tokens; "
+                                   + ("one layer per GPU" if args.mode == "layers" else "ONE layer, rows split over the GPUs"),
+                       "m": m, "n": n, "bits": args.bits, "ganq_iterations": K, "mode": args.mode,
+                       "parallelism": f"layers x{dist.world}" if args.mode == "layers" else f"rows /{dist.world}"},
             "column_steps_per_s": round(value * K, 1),
             "roofline": roof,
             "path_hbm": {"algorithmic_GB_per_layer": round(b_loop / 1e9, 3), "achieved_GBs": round(path_gbs, 2),
@@ -278,10 +348,16 @@ def main():
                             f"{dom_name} only (events between dependent launches cost idle time)",
             "setup": setup,
             "dists_last_step": [round(float(x), 6) for x in out[2].cpu().tolist()], "best_k": int(out[3]),
+            "parity": "this exact workload, K = 10, is checked against the CPU oracle by tests/test_hip_configs.py::"
+                      "test_bench_workload_k10_vs_oracle (indices bit-exact, codebooks <= 1e-5, row losses <= 1e-6)",
         }
         if dist.world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cap, args)
             result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
+        if dist.world == 1 and not args.no_lut:
+            del cap, ws  # free the layer before the rings of weights are allocated
+            torch.cuda.empty_cache()
+            result["lut_forward"] = lut_forward_report()
         print(json.dumps(result), flush=True)
     if dist.world > 1:
         td.barrier()

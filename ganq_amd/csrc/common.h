@@ -61,6 +61,7 @@ enum Opt : int {
     OPT_LUT_KS,
     OPT_H_EXT,
     OPT_SOLVE_VARIANT,
+    OPT_LUT_NT,
     OPT_COUNT
 };
 long long opt_get(int id);

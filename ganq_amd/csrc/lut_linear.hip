@@ -296,6 +296,214 @@ __global__ __launch_bounds__(NW * 64) void lut_mfma_kernel(const uint16_t* __res
     if (tid == 0) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next call
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Decode kernel (M <= 32), one memory round trip.  At decode sizes the packed weight of a layer (8 MB at 4096 x 4096 x
+// 4 bit) is smaller than the chip's bandwidth-latency product (8 TB/s x ~2 us = 16 MB): the kernel is bound by how many
+// loads it keeps in flight, not by bandwidth.  So: one workgroup of 16 waves per 16 (NT = 1) or 32 (NT = 2) output
+// features -- 256 workgroups at m = 4096, one per CU --, the waves split in_features among themselves, and every wave
+// issues ALL the weight words and activations of up to KC groups of 32 columns before it touches any of them (for
+// n = 4096: its whole share); the codebook table is built while they fly; the 16 partial tiles meet in LDS (fixed order:
+// deterministic) and wave 0 writes y.  The sparse outliers of a layer (CSR by output feature, ganq_outlier_ratio) are
+// added by the same launch: wave w takes the entries j = w (mod 16) of each feature into its accumulators before the
+// reduction, so y = round(LUT part + sparse part + bias) with one rounding, like the two-launch path.
+template <int BITS, int RT, bool BF16, int NT, int KC>
+__global__ __launch_bounds__(1024, (RT == 1 && NT == 1 && BITS != 3) ? 8 : 4) void lut_decode_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                          const uint16_t* __restrict__ lut, const uint16_t* __restrict__ bias,
+                                                          const float* __restrict__ addend, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ ocols, const uint16_t* __restrict__ ovals,
+                                                          int M, int m, int n, int kb_per_wave, uint16_t* __restrict__ y) {
+    constexpr int V = 1 << BITS;
+    constexpr int NW = 16;
+    constexpr bool STRADDLE = (8 * BITS) % 16 != 0;  // 3-bit: a lane's 24 bits can span two words
+    // tbl[t][e][lane]: codebook entry e of lane's feature in tile t, one dword slot per lane and entry (conflict-free).
+    // (A table of PAIRS -- one lookup per two weights, no packing arithmetic -- was measured and lost: building 64 KB of it
+    // per workgroup costs more than the shorter decode saves: 4096 x 4096 6.1 vs 5.7 us, 14336 x 4096 14.9 vs 14.1 us.)
+    __shared__ __attribute__((aligned(4096))) uint32_t tbl[NT][V][64];  // 4 KB alignment: see the v_perm addressing
+    __shared__ float red[NW - 1][NT][RT][4][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, q = lane >> 4;
+    const int o0 = blockIdx.x * (16 * NT);
+    const int nkb = n >> 5;
+    const int kb_begin = min(nkb, wv * kb_per_wave), kb_end = min(nkb, kb_begin + kb_per_wave);
+    const int off = 8 * BITS * q, wi = off >> 5, sh = off & 31;
+    const int wi2 = STRADDLE ? min(wi + 1, BITS - 1) : wi;
+    // features are dealt to (tile, lane) interleaved: tile t of lane `col` is feature o0 + NT col + t, so that the NT words
+    // a lane needs from one word row are adjacent in memory (one 8-byte load for NT = 2, 128-byte runs per 16 lanes)
+    int oc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) oc[t] = min(o0 + NT * col + t, m - 1);
+    // NT = 2 (the plan only picks it for even m): the pair's column, clamped so that a ragged last workgroup still loads
+    // inside the matrix (its surplus lanes compute features they never write)
+    const int cb = min(o0 + NT * col, m - NT);
+
+    // sparse outliers: this wave's share of each feature's entries (issued first: the longest dependent chain)
+    int o_beg[NT], o_end[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        o_beg[t] = o_end[t] = 0;
+        if (rowptr) {
+            o_beg[t] = rowptr[oc[t]] + wv;
+            o_end[t] = rowptr[oc[t] + 1];
+        }
+    }
+
+    uint32_t wl[KC][NT], wh[KC][NT];
+    u32x4 xa[KC][RT];
+    auto issue = [&](int kb0) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int kb = kb0 + c;
+            const bool ok = kb < kb_end;
+            const int kbc = ok ? kb : min(kb_begin, nkb - 1);
+            const int64_t row = (int64_t)(kbc * BITS + wi) * m, row2 = (int64_t)(kbc * BITS + wi2) * m;
+            if constexpr (NT == 2) {
+                const uint2 a = *reinterpret_cast<const uint2*>(qw + row + cb);
+                wl[c][0] = a.x;
+                wl[c][1] = a.y;
+                if (STRADDLE) {
+                    const uint2 b2 = *reinterpret_cast<const uint2*>(qw + row2 + cb);
+                    wh[c][0] = b2.x;
+                    wh[c][1] = b2.y;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    wl[c][t] = qw[row + oc[t]];
+                    if (STRADDLE) wh[c][t] = qw[row2 + oc[t]];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int xr = 16 * r + col;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok && xr < M) v = *reinterpret_cast<const u32x4*>(x + (int64_t)xr * n + 32 * kbc + 8 * q);
+                xa[c][r] = v;
+            }
+        }
+    };
+    f32x4 acc[NT][RT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kb_begin < kb_end) issue(kb_begin);  // everything this wave needs (n <= 32 * 16 * KC) is in flight from here on
+    {   // wave t fetches the V entries of every lane's feature of tile t and fills that tile's table
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (wv == t) {
+                const uint32_t* lp = reinterpret_cast<const uint32_t*>(lut + (int64_t)oc[t] * V);
+                uint32_t h[V / 2];
+#pragma unroll
+                for (int e = 0; e < V / 2; ++e) h[e] = lp[e];
+#pragma unroll
+                for (int e = 0; e < V / 2; ++e) {
+                    tbl[t][2 * e][lane] = h[e] & 0xffffu;
+                    tbl[t][2 * e + 1][lane] = h[e] >> 16;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint32_t tb0 = (uint32_t)(uintptr_t)(&tbl[0][0][0]);
+    const uint32_t lane4 = 4u * lane;
+    auto consume = [&]() {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            u32x4 b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint32_t bits = wl[c][t] >> sh;
+                if (STRADDLE) bits = (uint32_t)((((uint64_t)wh[c][t] << 32) | wl[c][t]) >> sh);
+                const uint32_t tb = tb0 + (uint32_t)t * (V * 256u);
+                if (BITS == 4) {
+                    // byte k of lo/hi = entry index of element 2k / 2k+1, OR-ed with byte 1 of the (4 KB aligned) tile base:
+                    // one v_perm per address ({byte1, byte0} = {index | base, 4*lane})
+                    const uint32_t hib = ((tb >> 8) & 0xffu) * 0x01010101u;
+                    const uint32_t lo = (bits & 0x0f0f0f0fu) | hib, hi = ((bits >> 4) & 0x0f0f0f0fu) | hib;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        b[t][p] = lds_pair(__builtin_amdgcn_perm(lo, lane4, 0x0c0c0000u | ((4u + p) << 8)),
+                                           __builtin_amdgcn_perm(hi, lane4, 0x0c0c0000u | ((4u + p) << 8)));
+                } else {
+                    const uint32_t base = tb + lane4;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        b[t][p] = lds_pair((((bits >> (BITS * (2 * p))) & (V - 1)) << 8) + base,
+                                           (((bits >> (BITS * (2 * p + 1))) & (V - 1)) << 8) + base);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (BF16)
+                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa[c][r]),
+                                                                            __builtin_bit_cast(bf16x8, b[t]), acc[t][r], 0, 0, 0);
+                    else
+                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xa[c][r]),
+                                                                           __builtin_bit_cast(f16x8, b[t]), acc[t][r], 0, 0, 0);
+                }
+        }
+    };
+    // groups past kb_end carry zero activations, so a ragged last round needs no special case
+    for (int kb0 = kb_begin; kb0 < kb_end; kb0 += KC) {
+        if (kb0 != kb_begin) issue(kb0);
+        consume();
+    }
+
+    // sparse part: D[row][feature] += x[row][c_j] * v_j over this wave's entries of the feature (fp32)
+    if (rowptr) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            for (int j = o_beg[t]; j < o_end[t]; j += NW) {
+                const int c = ocols[j];
+                const uint16_t vb = ovals[j];
+                const float v = BF16 ? __builtin_bit_cast(float, (uint32_t)vb << 16) : (float)__builtin_bit_cast(_Float16, vb);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 16 * r + 4 * q + i;
+                        if (row < M && o0 + NT * col + t < m) {
+                            const uint16_t xb = x[(int64_t)row * n + c];
+                            const float xv = BF16 ? __builtin_bit_cast(float, (uint32_t)xb << 16) : (float)__builtin_bit_cast(_Float16, xb);
+                            acc[t][r][i] = fmaf(xv, v, acc[t][r][i]);
+                        }
+                    }
+            }
+    }
+
+    if (wv > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[wv - 1][t][r][i][lane] = acc[t][r][i];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[t][r][i];
+#pragma unroll
+                for (int w2 = 0; w2 < NW - 1; ++w2) v += red[w2][t][r][i][lane];  // fixed order
+                const int row = 16 * r + 4 * q + i, o = o0 + NT * col + t;
+                if (row < M && o < m) {
+                    if (addend) v += addend[(int64_t)row * m + o];
+                    if (bias) v += BF16 ? __builtin_bit_cast(float, (uint32_t)bias[o] << 16) : (float)__builtin_bit_cast(_Float16, bias[o]);
+                    y[(int64_t)row * m + o] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v) : __builtin_bit_cast(uint16_t, (_Float16)v);
+                }
+            }
+}
+
 template <int BITS>
 __global__ __launch_bounds__(256) void lut_dequant_kernel(const uint32_t* __restrict__ qw, const void* __restrict__ lut,
                                                           int dtype, int m, int n, uint16_t* __restrict__ Wq) {
@@ -349,7 +557,8 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict_
 constexpr size_t LUT_COUNTER_BYTES = 64 * 1024;
 
 struct LutPlan {
-    bool inwg;  // the waves of a workgroup split in_features among themselves (no exchange through memory)
+    bool inwg;  // decode kernel: the 16 waves of a workgroup split in_features among themselves (no exchange through memory)
+    int nt;     // decode kernel: 16-feature tiles per workgroup (1: 256 workgroups at m = 4096; 2 from m = 8192)
     int ob, KS, kb_per_wg;
     size_t counter_bytes, bytes;
 };
@@ -359,10 +568,16 @@ static LutPlan lut_plan(int64_t M, int64_t m, int64_t n, int bits) {
     LutPlan p;
     const int nkb = (int)(n >> 5);
     const int inwg_env = (int)opt_get(OPT_LUT_INWG);
-    // enough 32-feature workgroups to occupy the chip, and a reduction buffer that fits LDS (two row tiles)
-    p.inwg = inwg_env >= 0 ? (inwg_env != 0 && M <= 32) : (M <= 32 && (m + 31) / 32 >= 96);
+    // enough workgroups to occupy the chip, and a reduction buffer that fits LDS (two row tiles)
+    p.inwg = inwg_env >= 0 ? (inwg_env != 0 && M <= 32) : (M <= 32 && m >= 1024);
+    p.nt = 1;
     if (p.inwg) {
-        p.ob = (int)((m + 31) / 32);
+        const int nt_opt = (int)opt_get(OPT_LUT_NT);
+        // 32 features per workgroup once that still gives every CU a workgroup (m >= 8192), or for more than one row of x
+        // when it gives at least half of them one (every workgroup reads all of x: twice the features halve that traffic)
+        p.nt = nt_opt > 0 ? (nt_opt >= 2 ? 2 : 1) : ((m + 31) / 32 >= 256 ? 2 : 1);
+        if ((m & 1) || M > 16) p.nt = 1;  // the pair loads of the 32-feature variant want an even row pitch; LDS (see launch)
+        p.ob = (int)((m + 16 * p.nt - 1) / (16 * p.nt));
         p.KS = 1;
         p.kb_per_wg = (nkb + LWK - 1) / LWK;  // per wave
         p.counter_bytes = LUT_COUNTER_BYTES;
@@ -401,9 +616,23 @@ extern "C" int ganq_lut_linear_workspace_init(void* workspace, size_t workspace_
     return 0;
 }
 
+struct LutCsr {  // sparse outliers of the layer (device pointers; rowptr == nullptr: none)
+    const int32_t* rowptr = nullptr;
+    const int32_t* cols = nullptr;
+    const uint16_t* vals = nullptr;
+};
+
+template <int BITS, int RT, bool BF16, int NT>
+static void launch_decode(const uint16_t* xp, const uint32_t* qw, const uint16_t* lp, const uint16_t* bp, const float* addend,
+                          const LutCsr& csr, int M, int m, int n, const LutPlan& p, uint16_t* yp, hipStream_t stream) {
+    constexpr int KC = RT == 1 ? 8 : 4;  // groups of 32 columns a wave has in flight (n = 4096: all 8 of its share)
+    hipLaunchKernelGGL((lut_decode_kernel<BITS, RT, BF16, NT, KC>), dim3((unsigned)p.ob), dim3(1024), 0, stream, xp, qw, lp, bp, addend,
+                       csr.rowptr, csr.cols, csr.vals, M, m, n, p.kb_per_wg, yp);
+}
+
 template <int BITS, int RT>
-static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, int dtype, int M,
-                         int m, int n,
+static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, const LutCsr& csr,
+                         int dtype, int M, int m, int n,
                          const LutPlan& p, float* partial, int* counters, void* y, hipStream_t stream) {
     const dim3 grid((unsigned)p.ob, (unsigned)p.KS);
     const uint16_t* xp = static_cast<const uint16_t*>(x);
@@ -412,17 +641,23 @@ static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, con
     uint16_t* yp = static_cast<uint16_t*>(y);
     if constexpr (RT <= 2) {
         if (p.inwg) {
-            const dim3 g1((unsigned)p.ob, 1);
-            if (dtype == 1)
-                hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true, LWK, true>), g1, dim3(LWK * 64), 0, stream, xp, qw, lp, bp, addend, M,
-                                   m, n, p.kb_per_wg, 1, partial, counters, yp);
-            else
-                hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, false, LWK, true>), g1, dim3(LWK * 64), 0, stream, xp, qw, lp, bp, addend, M,
-                                   m, n, p.kb_per_wg, 1, partial, counters, yp);
+            // 32 features per workgroup only with one row tile (the pair tables of two feature tiles plus the reduction
+            // buffer of two row tiles do not fit the LDS); the plan knows
+            if constexpr (RT == 1) {
+                if (p.nt == 2) {
+                    if (dtype == 1) launch_decode<BITS, RT, true, 2>(xp, qw, lp, bp, addend, csr, M, m, n, p, yp, stream);
+                    else launch_decode<BITS, RT, false, 2>(xp, qw, lp, bp, addend, csr, M, m, n, p, yp, stream);
+                    GANQ_LAUNCH_CHECK();
+                    return 0;
+                }
+            }
+            if (dtype == 1) launch_decode<BITS, RT, true, 1>(xp, qw, lp, bp, addend, csr, M, m, n, p, yp, stream);
+            else launch_decode<BITS, RT, false, 1>(xp, qw, lp, bp, addend, csr, M, m, n, p, yp, stream);
             GANQ_LAUNCH_CHECK();
             return 0;
         }
     }
+    if (csr.rowptr) return fail(-2, "ganq_lut_linear_fwd: the fused outlier path serves the decode kernel only");
     if (dtype == 1)
         hipLaunchKernelGGL((lut_mfma_kernel<BITS, RT, true, LW, false>), grid, dim3(LW * 64), 0, stream, xp, qw, lp, bp, addend, M, m, n,
                            p.kb_per_wg, p.KS, partial, counters, yp);
@@ -434,12 +669,12 @@ static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, con
 }
 
 template <int BITS>
-static int launch_lut(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, int dtype, int M,
-                      int m, int n,
+static int launch_lut(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, const LutCsr& csr,
+                      int dtype, int M, int m, int n,
                       const LutPlan& p, float* partial, int* counters, void* y, hipStream_t stream) {
-    if (M <= 16) return launch_lut_rt<BITS, 1>(x, qw, lut, bias, addend, dtype, M, m, n, p, partial, counters, y, stream);
-    if (M <= 32) return launch_lut_rt<BITS, 2>(x, qw, lut, bias, addend, dtype, M, m, n, p, partial, counters, y, stream);
-    return launch_lut_rt<BITS, 4>(x, qw, lut, bias, addend, dtype, M, m, n, p, partial, counters, y, stream);
+    if (M <= 16) return launch_lut_rt<BITS, 1>(x, qw, lut, bias, addend, csr, dtype, M, m, n, p, partial, counters, y, stream);
+    if (M <= 32) return launch_lut_rt<BITS, 2>(x, qw, lut, bias, addend, csr, dtype, M, m, n, p, partial, counters, y, stream);
+    return launch_lut_rt<BITS, 4>(x, qw, lut, bias, addend, csr, dtype, M, m, n, p, partial, counters, y, stream);
 }
 
 static int check_lut_args(const char* who, int dtype, int64_t m, int64_t n, int bits) {
@@ -452,7 +687,7 @@ static int check_lut_args(const char* who, int dtype, int64_t m, int64_t n, int 
 
 static int lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut, const void* bias, const float* addend, int dtype,
                           int64_t M, int64_t m, int64_t n, int bits, void* y, void* workspace, size_t workspace_bytes,
-                          void* stream_) {
+                          void* stream_, const LutCsr& csr = LutCsr()) {
     if (M < 0 || m < 0 || n < 0) return fail(-1, "ganq_lut_linear_fwd: negative shape");
     if (M == 0 || m == 0) return 0;
     int rc = check_lut_args("ganq_lut_linear_fwd", dtype, m, n, bits);
@@ -473,9 +708,9 @@ static int lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut
     float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.counter_bytes);
     const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
     ProfScope prof(KID_LUT_GEMV, stream);
-    if (bits == 2) rc = launch_lut<2>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
-    else if (bits == 3) rc = launch_lut<3>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
-    else rc = launch_lut<4>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    if (bits == 2) rc = launch_lut<2>(x, qw, lut, bias, addend, csr, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    else if (bits == 3) rc = launch_lut<3>(x, qw, lut, bias, addend, csr, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
+    else rc = launch_lut<4>(x, qw, lut, bias, addend, csr, dtype, (int)M, (int)m, (int)n, p, partial, counters, y, stream);
     return rc;
 }
 
@@ -512,6 +747,15 @@ extern "C" int ganq_lut_linear_fwd_outliers(const void* x, const int32_t* qweigh
     if (!workspace || workspace_bytes < base + (size_t)M * m * sizeof(float))
         return fail(-4, "ganq_lut_linear_fwd_outliers: workspace %zu B < required %zu B", workspace_bytes,
                     base + (size_t)M * m * sizeof(float));
+    if (n >= 32 && n % 32 == 0 && lut_plan(M, m, n, bits).inwg) {
+        // decode sizes: ONE launch -- the sparse entries are added inside the LUT kernel (lut_decode_kernel)
+        if (!rowptr) return fail(-3, "ganq_lut_linear_fwd_outliers: null rowptr");
+        LutCsr csr;
+        csr.rowptr = rowptr;
+        csr.cols = cols;
+        csr.vals = static_cast<const uint16_t*>(vals);
+        return lut_linear_fwd(x, qweight, lut, bias, nullptr, dtype, M, m, n, bits, y, workspace, base, stream_, csr);
+    }
     float* addend = reinterpret_cast<float*>(static_cast<char*>(workspace) + base);
     int rc = ganq_outlier_matmul(x, dtype, M, m, n, rowptr, cols, vals, addend, stream_);
     if (rc) return rc;

@@ -7,8 +7,8 @@ Differences from the reference processor:
     the per-module result, because the LUT layer is built from them (the reference result only carries
     {"scale","zero","g_idx"}, gptq_processor.py:172-176);
   * quantized weights stay on the GPU (the reference moves every `wq` to the CPU, :196-199);
-  * `finalize` swaps nn.Linear -> GanqHipQuantLinear directly (the reference goes through pack_model ->
-    make_quant -> select_quant_linear, utils/model.py:573-639; INTEGRATION.md shows that registration).
+  * `finalize` packs through ganq_amd/nn_modules/backend.py, the reference's pack_model -> make_quant ->
+    select_quant_linear -> create_quant_layer path (utils/model.py:573-639) with BACKEND.GANQ_HIP registered.
 """
 import copy
 import time
@@ -17,7 +17,6 @@ from typing import Callable, Dict, Tuple
 import torch
 import torch.nn as nn
 
-from ..nn_modules.qlinear.ganq_hip import GanqHipQuantLinear
 from ..quantization.config import FORMAT, QUANT_METHOD, QuantizeConfig
 from ..quantization.ganq import GANQ
 from .named_module import NamedModule
@@ -86,23 +85,12 @@ class GPTQProcessor:
     def results(self):
         return self._results
 
-    def finalize(self, model: nn.Module, **kwargs):
-        """replace every quantized nn.Linear by a packed GanqHipQuantLinear (FORMAT.GANQ_LUT)"""
-        if self.qcfg.format != FORMAT.GANQ_LUT:
-            return model  # FORMAT.FAKE: the dequantised weights already sit in the nn.Linear modules
-        named = dict(model.named_modules())
-        for full_name, res in self._results.items():
-            lin = named[full_name]
-            is_conv1d = type(lin).__name__ == "Conv1D"
-            in_f = lin.weight.shape[0] if is_conv1d else lin.in_features
-            out_f = lin.weight.shape[1] if is_conv1d else lin.out_features
-            q = GanqHipQuantLinear(bits=res["bits"], group_size=self.qcfg.group_size, sym=self.qcfg.sym,
-                                   desc_act=self.qcfg.desc_act, in_features=in_f, out_features=out_f,
-                                   bias=lin.bias is not None, pack_dtype=self.qcfg.pack_dtype, name=full_name,
-                                   outliers=0 if res.get("ganq_outliers") is None else int(res["ganq_outliers"][1].numel()))
-            q = q.to(lin.weight.device)
-            q.pack(lin, res["scale"], res["zero"], res["g_idx"], ganq_indices=res["ganq_q"], ganq_codebook=res["ganq_lut"],
-                   ganq_outliers=res.get("ganq_outliers"))
-            parent_name, _, child = full_name.rpartition(".")
-            setattr(named[parent_name] if parent_name else model, child, q)
+    def finalize(self, model: nn.Module, backend=None, **kwargs):
+        """FORMAT.GANQ_LUT: replace every quantized nn.Linear by a packed QuantLinear, through the same steps as the
+        reference's pack path (pack_model -> make_quant -> select_quant_linear -> create_quant_layer -> pack_module,
+        utils/model.py:573-639): ganq_amd/nn_modules/backend.py.  FORMAT.FAKE: the dequantised weights already sit in
+        the nn.Linear modules."""
+        from ..nn_modules.backend import BACKEND, pack_model
+
+        pack_model(model, quant_result=self._results, qcfg=self.qcfg, backend=backend or BACKEND.AUTO)
         return model

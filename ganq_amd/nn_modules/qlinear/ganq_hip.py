@@ -88,7 +88,9 @@ class GanqHipQuantLinear(BaseQuantLinear):
         W = linear.weight.data
         if type(linear).__name__ == "Conv1D":
             W = W.t()
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = self.qweight.device  # the packing kernel runs where the layer lives
+        if dev.type != "cuda":
+            dev = W.device if W.is_cuda else torch.device("cuda", torch.cuda.current_device())
         if self.outliers and ganq_outliers is None:
             raise ValueError("a layer with outliers cannot be recovered from its weight: pass ganq_outliers=")
         if ganq_indices is None or ganq_codebook is None:

@@ -78,6 +78,9 @@ class QuantizeConfig:
     # not in the reference code (paper section 3.3 / Appendix A, "GANQ*"): fraction r of every weight row kept exactly
     # as sparse fp16 outliers (row-wise, beyond the 1 - r/2 and r/2 quantiles); GANQ quantizes the rest.  0 = off.
     ganq_outlier_ratio: float = field(default=0.0)
+    # not in the reference: calibration batches are handed to the Hessian kernel in groups of up to this many tokens
+    # (one read-modify-write of H per group instead of per batch; same H up to fp32 summation order).  0 = per batch.
+    ganq_hessian_stage_tokens: int = field(default=16384)
 
     def __post_init__(self):
         info = fields(self)

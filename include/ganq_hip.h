@@ -180,7 +180,7 @@ int ganq_outlier_matmul(const void* x, int dtype, int64_t M, int64_t m, int64_t 
 /* ---- developer / test switches.  They are read from the environment (variable == option name) once, when the library
  * is loaded; afterwards only these calls change them -- the compute entry points never call getenv().  Options:
  * GANQ_T_FULL, GANQ_T_INCR_THR, GANQ_T_JACOBI, GANQ_SOLVE_ALL_ROWS, GANQ_MUPDATE_LDS, GANQ_WH_F64, GANQ_KMEANS_WCAP,
- * GANQ_CHOL_LOOKAHEAD, GANQ_ACCUM_DEBUG, GANQ_LUT_INWG, GANQ_LUT_WGS, GANQ_LUT_KS, GANQ_H_EXT, GANQ_SOLVE_VARIANT
+ * GANQ_CHOL_LOOKAHEAD, GANQ_ACCUM_DEBUG, GANQ_LUT_INWG, GANQ_LUT_WGS, GANQ_LUT_KS, GANQ_LUT_NT, GANQ_H_EXT, GANQ_SOLVE_VARIANT
  * (meanings: ganq_amd/csrc/runtime.hip).  None of them changes a result except where a test says so. */
 int ganq_debug_set_option(const char* name, long long value);
 int ganq_debug_get_option(const char* name, long long* value);

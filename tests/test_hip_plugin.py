@@ -55,7 +55,7 @@ def test_quantize_seven_tuple_vs_reference(name, prologue):
     for xb in g["X"]:
         q.add_batch(torch.from_numpy(xb).cuda(), None)
     assert q.nsamples == int(g["nsamples"]) and q.fwd_counter == g["X"].shape[0]
-    assert rel_fro(q.H.cpu().numpy(), g["H_raw"]) < 1e-6
+    assert rel_fro(q.hessian.cpu().numpy(), g["H_raw"]) < 1e-6
     wq, scale, zero, g_idx, duration, avg_loss, damp = q.quantize()
     assert wq.dtype == torch.float16 and wq.shape == lin.weight.shape and wq.is_cuda
     assert np.array_equal(g_idx.cpu().numpy(), g["g_idx"].reshape(-1)) and g_idx.dtype == torch.int32
@@ -163,7 +163,7 @@ def test_damp_retry_on_indefinite_hessian(prologue):
         q = GANQ(NamedModule(lin, "fc", "layers.0.fc", 0), qcfg)
         q.quantizer.configure(perchannel=True)
         q.add_batch(X, None)
-        q.H -= 0.05 * torch.diag(q.H).mean() * torch.eye(n, device="cuda")  # push the null space below zero
+        q.hessian.sub_(0.05 * torch.diag(q.hessian).mean() * torch.eye(n, device="cuda"))  # push the null space below zero
         return q.quantize()
 
     with pytest.raises(torch.linalg.LinAlgError):
@@ -378,3 +378,35 @@ def test_quantlinear_pack_forward_and_state_dict(bits, rows):
     ql2.load_state_dict(ql.state_dict())
     assert torch.equal(ql2(x), y)
     assert ql.qweight.numel() * 4 + ql.lut.numel() * 2 < lin.weight.numel() * 2 * (bits + 1) / 16 + 4096
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_hessian_staging_equals_per_batch_accumulation(dtype):
+    """calibration batches handed to the Hessian kernel in groups (QuantizeConfig.ganq_hessian_stage_tokens) give the H of
+    the per-batch running average (gptq.py:96-131) -- the decay factors telescope -- up to fp32 summation order"""
+    from ganq_amd.looper.named_module import NamedModule
+    from ganq_amd.quantization import GANQ, QuantizeConfig
+    from oracle import c_oracle
+
+    torch.manual_seed(0)
+    n, m = 384, 32
+    lin = nn.Linear(n, m, bias=False).to(dtype).cuda()
+    shapes = [(1, 100), (2, 64), (1, 300), (3, 50), (1, 37), (2, 128), (1, 700)]
+    xs = [torch.randn(b, s, n, device="cuda").to(dtype) * (0.1 + torch.rand(n, device="cuda")).to(dtype) for b, s in shapes]
+    hs = {}
+    for stage in (0, 256, 16384):
+        q = GANQ(NamedModule(lin, "fc", "layers.0.fc", 0), QuantizeConfig(bits=4, ganq_hessian_stage_tokens=stage))
+        q.quantizer.configure(perchannel=True)
+        for x in xs:
+            q.add_batch(x, None)
+        assert q.nsamples == sum(b for b, _ in shapes) and q.fwd_counter == len(xs)
+        hs[stage] = q.hessian.clone()
+    for stage in (256, 16384):
+        assert rel_fro(hs[stage].cpu().numpy(), hs[0].cpu().numpy()) < 1e-6, stage
+    if dtype == torch.float16:
+        Ho = np.zeros((n, n), dtype=np.float32)
+        N = 0
+        for x in xs:
+            c_oracle.hessian_accum(Ho, x.reshape(-1, n).cpu().numpy(), N, x.shape[0])
+            N += x.shape[0]
+        assert rel_fro(hs[16384].cpu().numpy(), Ho) < 1e-6

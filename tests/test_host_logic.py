@@ -163,3 +163,21 @@ def test_row_sharded_two_ranks_gloo(name, alias):
         assert np.linalg.norm(T - g["T"][best + 1]) / np.linalg.norm(g["T"][best + 1]) < 1e-5
         assert np.array_equal(xb, np.arange(12.0).reshape(3, 4)) and np.all(Hp == 3.0)
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_backend_registration_selects_the_lut_layer():
+    """BACKEND / FORMAT_DICT / select_quant_linear as code (utils/importer.py:45-68,157-262 of the reference)"""
+    from ganq_amd.nn_modules.backend import AUTO_SELECT_BACKEND_ORDER, BACKEND, FORMAT_DICT, select_quant_linear
+    from ganq_amd.nn_modules.qlinear.ganq_hip import GanqHipQuantLinear
+    from ganq_amd.quantization.config import FORMAT
+
+    assert FORMAT_DICT[FORMAT.GANQ_LUT] == [BACKEND.GANQ_HIP] and FORMAT_DICT[FORMAT.FAKE] == []
+    assert AUTO_SELECT_BACKEND_ORDER[BACKEND.GANQ_HIP] is GanqHipQuantLinear
+    for bits in (2, 3, 4):
+        assert select_quant_linear(bits, 128, True, True, format=FORMAT.GANQ_LUT) is GanqHipQuantLinear
+        assert select_quant_linear(bits, -1, False, True, backend=BACKEND.GANQ_HIP, format=FORMAT.GANQ_LUT,
+                                   multi_select=True) == [GanqHipQuantLinear]
+    with pytest.raises(NotImplementedError):  # validate() refuses, so an AUTO caller would fall through (utils/model.py:234-239)
+        select_quant_linear(8, 128, True, True, format=FORMAT.GANQ_LUT)
+    with pytest.raises(ValueError):
+        select_quant_linear(4, 128, True, True, backend=BACKEND.GANQ_HIP, format=FORMAT.FAKE)
