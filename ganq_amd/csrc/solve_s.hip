@@ -50,6 +50,17 @@ __device__ __forceinline__ uint32_t row_or_u(uint32_t x) {
     return x;
 }
 
+// value for the lanes (l & 15) == OWN of every 16-lane row, `old` elsewhere: the lane mask is a compile-time constant, so
+// it is materialised by two scalar moves where it is used instead of living in a register pair for the whole panel (the
+// 16 masks of a panel, kept live, were most of the kernel's scalar-register pressure)
+template <int OWN>
+__device__ __forceinline__ uint32_t sel_own(uint32_t old, uint32_t nw) {
+    const unsigned long long mask = 0x0001000100010001ull << OWN;
+    uint32_t out;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(old), "v"(nw), "s"(mask));
+    return out;
+}
+
 struct PanelState {
     float r[4];     // running residual sums of this lane's 4 panel columns (c16 + 16k)
     float w[4];     // W[row][j0 + c16 + 16k]
@@ -58,6 +69,180 @@ struct PanelState {
     float tv;       // T[row][c16] (+inf beyond V)
     uint32_t c16;
 };
+
+// ---- threshold form of the argmin (fast path of the panel steps) ---------------------------------------------------
+// The step's cost is its DPP instructions (a lone wave issues one every ~12 cycles, and they do not overlap with the
+// other role's MFMAs on the SIMD): the three 16-lane reductions of panel_step are 12 of its 14.  With the row's codebook
+// SORTED, lane s holding the s-th smallest value t_s (and its original index), the first minimum of |eff - T[v]| is
+// decided by per-lane thresholds instead: lo_s / hi_s are the exact fp32 switch-over points between t_s and its
+// neighbours, found once per launch by bisection on the kernel's own predicate
+//     "the right neighbour wins":  |RN(x - b)| < |RN(x - a)|,  or equal and b has the smaller ORIGINAL index
+// (monotone in x: RN is monotone), and lane s is the argmin iff  lo_s < eff <= hi_s.  That needs no cross-lane step; only
+// T[idx] is then broadcast by ONE reduction (6 DPP per step instead of 14).  Equal values are merged (lowest original
+// index represents them).  The argument needs every distance to be rounded without collisions, which holds while
+// |eff| <= xb := 2^22 * (smallest gap between distinct values) - max|T|; a step outside that range -- or a NaN, or a row
+// whose codebook has near-duplicates -- selects no lane or several, the wave notices (popcount of the selection != 4
+// rows) and the whole panel is redone by the reduction path.  Results are bit-identical either way
+// (tests/test_hip_stages.py: unsorted codebooks, duplicates, exact mid-point ties, out-of-range residuals).
+typedef uint32_t __attribute__((address_space(3))) lds_u32_t;
+typedef uint8_t __attribute__((address_space(3))) lds_u8_t;
+
+#ifdef GANQ_SOLVE_DEBUG
+__device__ unsigned long long g_solve_dbg[4];  // [0] panels on the fast path, [1] panels redone, [2] waves without fast path
+#endif
+
+struct FastRow {
+    float tv;       // sorted value held by this lane (t_s)
+    float lo, hi;   // lane s is the argmin iff lo <= eff <= hi (closed, already clamped to [-xb, xb]); lo = hi = +inf: never
+    float xb;       // > 0: the row can use the thresholds
+    uint32_t orig;  // original index of t_s
+};
+
+__device__ __forceinline__ uint32_t f2ord(float f) {  // order-preserving map float -> uint32
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    const uint32_t b = o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu);
+    return __builtin_bit_cast(float, b);
+}
+// does b (right neighbour, original index ob) beat a (original index oa) at x, by the kernel's own comparison?
+__device__ __forceinline__ bool right_wins(float x, float a, uint32_t oa, float b, uint32_t ob) {
+    const uint32_t da = __builtin_bit_cast(uint32_t, x - a) & 0x7fffffffu;
+    const uint32_t db = __builtin_bit_cast(uint32_t, x - b) & 0x7fffffffu;
+    return db < da || (db == da && ob < oa);
+}
+
+// rotation by K lanes within the 16-lane DPP row (row_ror); value and lane index are rotated together, so the direction
+// does not matter to the caller
+template <int K>
+__device__ __forceinline__ uint32_t row_rot(uint32_t x) {
+    return dpp_u<0x120 + K>(x);
+}
+
+// One-time setup per launch: sort the row's codebook across its 16 lanes, merge equal values, find the thresholds.
+// `scratch` is 16 x 2 dwords of LDS private to this 16-lane row.  Returns false (for the whole row) when the row cannot
+// use the fast path.
+__device__ __forceinline__ FastRow fast_row_setup(float tv_orig, uint32_t c16, volatile lds_u32_t* scratch) {
+    // rank by (value, original index): strict total order, stable; -0 and +0 are one value (they compare equal)
+    uint32_t rank = 0;
+    const uint32_t myo = f2ord(tv_orig == 0.0f ? 0.0f : tv_orig);
+    auto count = [&](uint32_t oo, uint32_t ol) { rank += (oo < myo || (oo == myo && ol < c16)) ? 1u : 0u; };
+#define GANQ_ROT(K) count(row_rot<K>(myo), row_rot<K>(c16))
+    GANQ_ROT(1); GANQ_ROT(2); GANQ_ROT(3); GANQ_ROT(4); GANQ_ROT(5); GANQ_ROT(6); GANQ_ROT(7); GANQ_ROT(8);
+    GANQ_ROT(9); GANQ_ROT(10); GANQ_ROT(11); GANQ_ROT(12); GANQ_ROT(13); GANQ_ROT(14); GANQ_ROT(15);
+#undef GANQ_ROT
+    scratch[2 * rank] = __builtin_bit_cast(uint32_t, tv_orig);
+    scratch[2 * rank + 1] = c16;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    FastRow fr;
+    fr.tv = __builtin_bit_cast(float, (uint32_t)scratch[2 * c16]);
+    fr.orig = scratch[2 * c16 + 1];
+    // neighbours in sorted order (lane c16 - 1 / c16 + 1); row ends see themselves
+    const float tprev = __builtin_bit_cast(float, (uint32_t)scratch[2 * (c16 > 0 ? c16 - 1 : 0)]);
+    // representative of a run of equal values = its first lane (lowest original index, by the sort order)
+    const bool rep = c16 == 0 || !(tprev == fr.tv);
+    // next DISTINCT value and the original index of its representative (inf entries beyond V are ordinary values here:
+    // they are never chosen while eff is finite, and a non-finite eff leaves the fast path)
+    float tnext = __builtin_inff();
+    uint32_t onext = 0;
+    bool has_next = false;
+    for (int s2 = 15; s2 >= 1; --s2) {  // scan from the far end so that the nearest distinct value is kept last
+        const int pos = (int)c16 + s2;
+        if (pos < 16) {
+            const float cand = __builtin_bit_cast(float, (uint32_t)scratch[2 * pos]);
+            if (cand > fr.tv) {
+                tnext = cand;
+                onext = scratch[2 * pos + 1];
+                has_next = true;
+            }
+        }
+    }
+    // the representative of the next distinct value is its FIRST lane: the scan above ends on the nearest position
+    // greater than tv, which is that first lane
+    float hi = __builtin_inff();
+    if (has_next && fr.tv == fr.tv && tnext < __builtin_inff()) {
+        // largest x in [tv, tnext] at which the right neighbour does not win yet (it does not at x = tv, it does at tnext)
+        uint32_t lo_o = f2ord(fr.tv), hi_o = f2ord(tnext);
+        while (hi_o - lo_o > 1u) {
+            const uint32_t mid = lo_o + ((hi_o - lo_o) >> 1);
+            if (right_wins(ord2f(mid), fr.tv, fr.orig, tnext, onext)) hi_o = mid; else lo_o = mid;
+        }
+        hi = ord2f(lo_o);
+    }
+    // lo of lane s = hi of the previous DISTINCT value's representative; pass it along through the scratch
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    scratch[2 * c16] = __builtin_bit_cast(uint32_t, hi);
+    scratch[2 * c16 + 1] = rep ? 1u : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float lo = -__builtin_inff();
+    for (int pos = 0; pos < 16; ++pos)  // the nearest representative to the left
+        if (pos < (int)c16 && scratch[2 * pos + 1] != 0u) lo = __builtin_bit_cast(float, (uint32_t)scratch[2 * pos]);
+    // gaps between distinct FINITE values and the largest finite magnitude -> range in which no two distances collide
+    const bool finite = fr.tv < __builtin_inff() && fr.tv > -__builtin_inff();
+    float gap = __builtin_inff();
+    if (rep && finite && has_next && tnext < __builtin_inff()) gap = tnext - fr.tv;
+    uint32_t gmin = __builtin_bit_cast(uint32_t, gap), amax = finite ? (__builtin_bit_cast(uint32_t, fr.tv) & 0x7fffffffu) : 0u;
+    gmin = row_min_u(gmin);                       // positive floats order like their bits
+    amax = 0xffffffffu - row_min_u(0xffffffffu - amax);
+    const float g = __builtin_bit_cast(float, gmin), a = __builtin_bit_cast(float, amax);
+    fr.xb = (g < __builtin_inff()) ? (4194304.0f * g - a) : 3.0e38f;  // one distinct value: nothing can collide
+    const bool nan_any = row_or_u((tv_orig != tv_orig) ? 1u : 0u) != 0u;
+    if (nan_any || !(fr.xb > 0.0f)) fr.xb = -1.0f;                    // never satisfied: the row stays on the slow path
+    // closed interval [next float above lo, hi], clamped to the collision-free range; an empty or unusable one becomes
+    // [+inf, +inf], which no finite eff lies in (one v_med3 + one compare per step test the membership)
+    float lo_c = lo == -__builtin_inff() ? -fr.xb : fmaxf(ord2f(f2ord(lo) + 1u), -fr.xb);
+    float hi_c = fminf(hi, fr.xb);
+    if (!rep || !(fr.tv < __builtin_inff()) || !(lo_c <= hi_c) || !(fr.xb > 0.0f)) {
+        lo_c = __builtin_inff();  // merged duplicates, the +inf padding, rows without a usable range
+        hi_c = __builtin_inff();
+    }
+    fr.lo = lo_c;
+    fr.hi = hi_c;
+    return fr;
+}
+
+// One column step on the fast path.  nsel counts this lane's selections: the intervals of a row are disjoint, so "every
+// step selected exactly one lane" is equivalent to "the row's selections add up to the number of steps", which the
+// caller checks once per panel (no scalar work inside the step).
+template <int JJ>
+__device__ __forceinline__ void panel_step_fast(PanelState& st, const FastRow& fr, const float2 dg, const float4 lrow,
+                                                uint32_t qaddr, uint32_t qdummy, uint32_t& nsel) {
+    constexpr int KREG = JJ >> 4, OWN = JJ & 15;
+    const float q0 = st.r[KREG] * dg.y;
+    const float qe = fmaf(-q0, dg.x, st.r[KREG]);
+    const float quo = fmaf(qe, dg.y, q0);
+    const float eff_l = st.w[KREG] + quo;
+    const float eff = dpp_f<0x150 + OWN>(eff_l);
+    const float wj = dpp_f<0x150 + OWN>(st.w[KREG]);
+    const bool sel = __builtin_amdgcn_fmed3f(eff, fr.lo, fr.hi) == eff;  // lo <= eff <= hi (false for NaN)
+    const uint32_t tb = row_or_u(sel ? __builtin_bit_cast(uint32_t, fr.tv) : 0u);
+    const float err = wj - __builtin_bit_cast(float, tb);
+    st.r[0] = fmaf(err, lrow.x, st.r[0]);
+    st.r[1] = fmaf(err, lrow.y, st.r[1]);
+    st.r[2] = fmaf(err, lrow.z, st.r[2]);
+    st.r[3] = fmaf(err, lrow.w, st.r[3]);
+    nsel += sel ? 1u : 0u;
+    // the selected lane files the ORIGINAL index of its value; the others write a dummy byte (no exec-mask change)
+    *reinterpret_cast<lds_u8_t*>((uintptr_t)(sel ? qaddr + JJ : qdummy)) = (uint8_t)fr.orig;
+    st.e[KREG] = __builtin_bit_cast(float, sel_own<OWN>(__builtin_bit_cast(uint32_t, st.e[KREG]), __builtin_bit_cast(uint32_t, err)));
+}
+
+template <bool FULL, int JJ>
+__device__ __forceinline__ void panel_from_fast(PanelState& st, const FastRow& fr, const float4 (*Ld)[16], const float2* Dg, int wd,
+                                                float2 dg, float4 lrow, uint32_t qaddr, uint32_t qdummy, uint32_t& nsel) {
+    float2 dg_n = dg;
+    float4 lrow_n = lrow;
+    if constexpr (JJ > 0) {
+        dg_n = Dg[JJ - 1];
+        lrow_n = Ld[JJ - 1][st.c16];
+    }
+    if (FULL || JJ < wd) panel_step_fast<JJ>(st, fr, dg, lrow, qaddr, qdummy, nsel);
+    if constexpr (JJ > 0) panel_from_fast<FULL, JJ - 1>(st, fr, Ld, Dg, wd, dg_n, lrow_n, qaddr, qdummy, nsel);
+}
 
 // One column step.  JJ = column inside the panel; its owner is lane (JJ & 15) of each DPP row, register JJ >> 4.
 // dg = {L[j][j], RN(1 / L[j][j])} and lrow = L[j][j0 + c16 + 16k] (k = 0..3) were read from LDS one step earlier.
@@ -87,10 +272,8 @@ __device__ __forceinline__ void panel_step(PanelState& st, const float2 dg, cons
     st.r[1] = fmaf(err, lrow.y, st.r[1]);
     st.r[2] = fmaf(err, lrow.z, st.r[2]);
     st.r[3] = fmaf(err, lrow.w, st.r[3]);
-    if (st.c16 == (uint32_t)OWN) {
-        st.q[KREG] = idx;
-        st.e[KREG] = err;
-    }
+    st.q[KREG] = sel_own<OWN>(st.q[KREG], idx);
+    st.e[KREG] = __builtin_bit_cast(float, sel_own<OWN>(__builtin_bit_cast(uint32_t, st.e[KREG]), __builtin_bit_cast(uint32_t, err)));
 }
 
 // steps run from the panel's last column down to its first; the LDS operands of step JJ-1 are fetched before the
@@ -168,11 +351,14 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                                                       const float* __restrict__ T, int m, int n, int V,
                                                       uint8_t* __restrict__ Q, float* __restrict__ ErrOut,
                                                       float* __restrict__ ErrT, int pbase, const int* __restrict__ rowlist,
-                                                      const int* __restrict__ nactive) {
+                                                      const int* __restrict__ nactive, int opt_fast) {
     __shared__ float4 Ld[2][SB][16];      // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
     __shared__ float Rp[2][SR][SB + 4];   // residual panel handed from (G) to (P)
     __shared__ float2 Dg[2][SB];          // {L[j][j], 1 / L[j][j]} of the panel's columns
     __shared__ __align__(16) float ErrPk[1024];  // packed Err block of the panel just solved (zero beyond its width)
+    __shared__ uint8_t Qst[4][4][SB];            // fast path: original index filed by the selected lane, per (P wave, row, step)
+    __shared__ uint32_t Qdm[4][64];              // ... and where the lanes that were NOT selected put theirs: one dword slot per
+                                                 // lane (60 lanes storing to ONE address would serialise in the LDS)
     extern __shared__ __align__(16) float ErrL[];  // packed Err blocks of the panels >= pbase, the A operand's hot part
 
     const int tid = threadIdx.x;
@@ -199,6 +385,17 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
     st.c16 = (uint32_t)c16;
     st.tv = (c16 < V) ? T[(int64_t)prow * V + c16] : __builtin_inff();
     float wnext[4] = {0.f, 0.f, 0.f, 0.f};
+    // (P) threshold form of the argmin: sorted codebook, exact switch-over points (see FastRow); ErrPk is free until the
+    // first panel has been solved and serves as the sort's scratch (32 dwords per 16-lane row)
+    FastRow fr = {};
+    bool fast_ok = false;
+    if (!roleG) {
+        fr = fast_row_setup(st.tv, (uint32_t)c16,
+                            reinterpret_cast<volatile lds_u32_t*>((lds_u32_t*)(uintptr_t)(uint32_t)(uintptr_t)ErrPk) + 32 * (4 * gw + rsub));
+        fast_ok = __ballot(fr.xb > 0.0f) == ~0ull && opt_fast;  // all four rows of the wave
+    }
+    const uint32_t qaddr = (uint32_t)(uintptr_t)&Qst[gw][rsub][0], qdummy = (uint32_t)(uintptr_t)&Qdm[gw][lane];
+    lds_u8_t* qstage = (lds_u8_t*)(uintptr_t)qaddr;
 
     // (P) where this lane's four Err values go inside a packed block: column col = c16 + 16 k is k-group col >> 2,
     // slot col & 3, i.e. MFMA lane (ksub, row)
@@ -211,8 +408,98 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
         pk_idx[k] = (g >> 2) * 256 + (ksub_w * 16 + prow_in_tile) * 4 + (g & 3);
     }
 
+    // The two roles run SEPARATE loops with the same number of barriers (s_barrier counts arrivals, not places): the
+    // registers of one role are then not live in the other's loop, and the kernel needs max(P, G) of them instead of
+    // the sum.
+    if (!roleG) {
+        for (int s = 0; s <= nb; ++s) {
+            const int bP = nb - s;  // panel solved in this step (none at s = 0)
+                // ---- (P) ---------------------------------------------------------------------------------------
+                if (bP <= nb - 1) {
+                    const int j0 = bP * SB;
+                    const int wd = min(SB, n - j0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        st.w[k] = wnext[k];
+                        st.q[k] = 0;
+                        st.e[k] = 0.0f;
+                        st.r[k] = Rp[bP & 1][prow_in_tile][c16 + 16 * k];
+                    }
+                    if (bP >= 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wnext[k] = W[(int64_t)prow * n + j0 - SB + c16 + 16 * k];  // full panel
+                    }
+#ifndef GANQ_SOLVE_NO_P  // timing experiment: results are meaningless without the panel steps
+                    bool bad = !fast_ok;
+                    if (fast_ok) {
+                        const float4(*Ldp)[16] = Ld[bP & 1];
+                        const float2* Dgp = Dg[bP & 1];
+                        uint32_t nsel = 0;
+#ifdef GANQ_SOLVE_DEBUG
+                        const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+#endif
+                        if (wd == SB) panel_from_fast<true, SB - 1>(st, fr, Ldp, Dgp, wd, Dgp[SB - 1], Ldp[SB - 1][st.c16], qaddr, qdummy, nsel);
+                        else panel_from_fast<false, SB - 1>(st, fr, Ldp, Dgp, wd, Dgp[SB - 1], Ldp[SB - 1][st.c16], qaddr, qdummy, nsel);
+#ifdef GANQ_SOLVE_DEBUG
+                        if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_solve_dbg[3], __builtin_amdgcn_s_memtime() - t_in);
+#endif
+                        // every step of every row selected exactly one lane <=> each row's selections add up to the step count
+                        nsel += dpp_u<0xB1>(nsel);
+                        nsel += dpp_u<0x4E>(nsel);
+                        nsel += dpp_u<0x141>(nsel);
+                        nsel += dpp_u<0x140>(nsel);
+                        bad = __ballot(nsel != (uint32_t)wd) != 0ull;
+                        if (!bad) {
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) st.q[k] = qstage[c16 + 16 * k];
+                        }
+                    }
+#ifdef GANQ_SOLVE_DEBUG
+                if (lane == 0) atomicAdd(&g_solve_dbg[fast_ok ? (bad ? 1 : 0) : 2], 1ull);
+#endif
+                if (bad) {  // wave-uniform: a step left the range the thresholds are exact in (or the row never had one)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            st.q[k] = 0;
+                            st.e[k] = 0.0f;
+                            st.r[k] = Rp[bP & 1][prow_in_tile][c16 + 16 * k];
+                        }
+                        if (wd == SB) {
+                            panel_all<true>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
+                        } else {
+                            panel_all<false>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
+                        }
+                    }
+#endif
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int col = c16 + 16 * k;
+                        const float ev = (col < wd) ? st.e[k] : 0.0f;  // the (partial) top panel is zero beyond n
+                        ErrPk[pk_idx[k]] = ev;
+                        // the block lives in LDS (panels >= pbase, never read back from memory) or in the global scratch
+                        if (bP >= pbase) ErrL[(bP - pbase) * 1024 + pk_idx[k]] = ev;
+                        else errt[bP * 1024 + pk_idx[k]] = ev;
+                        if (col < wd && prow_ok) {
+                            Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
+                            if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
+                        }
+                    }
+                } else {
+                    const int j0 = (nb - 1) * SB;  // W of the first (possibly partial) panel
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int col = c16 + 16 * k;
+                        wnext[k] = (j0 + col < n) ? W[(int64_t)prow * n + j0 + col] : 0.0f;
+                    }
+                }
+            __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
+            __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
+        }
+        return;
+    }
     for (int s = 0; s <= nb; ++s) {
-        const int bP = nb - s;      // panel solved in this step (none at s = 0)
         const int bG = nb - 1 - s;  // panel whose residual is produced in this step (none at s = nb)
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         f32x4v bpre[4];  // (G) packed L block (source panel bG+1, this wave's tile): the B operands of part 2
@@ -279,59 +566,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                 GANQ_PIN();
             }
         };
-        if (!roleG) {
-            // ---- (P) ---------------------------------------------------------------------------------------
-            if (bP <= nb - 1) {
-                const int j0 = bP * SB;
-                const int wd = min(SB, n - j0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    st.w[k] = wnext[k];
-                    st.q[k] = 0;
-                    st.e[k] = 0.0f;
-                    st.r[k] = Rp[bP & 1][prow_in_tile][c16 + 16 * k];
-                }
-                if (bP >= 1) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) wnext[k] = W[(int64_t)prow * n + j0 - SB + c16 + 16 * k];  // full panel
-                }
-#ifndef GANQ_SOLVE_NO_P  // timing experiment: results are meaningless without the panel steps
-                if (wd == SB) {
-                    panel_all<true>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
-                } else {
-                    panel_all<false>(st, Ld[bP & 1], Dg[bP & 1], wd, std::make_integer_sequence<int, SB>{});
-                }
-#endif
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int col = c16 + 16 * k;
-                    const float ev = (col < wd) ? st.e[k] : 0.0f;  // the (partial) top panel is zero beyond n
-                    ErrPk[pk_idx[k]] = ev;
-                    // the block lives in LDS (panels >= pbase, never read back from memory) or in the global scratch
-                    if (bP >= pbase) ErrL[(bP - pbase) * 1024 + pk_idx[k]] = ev;
-                    else errt[bP * 1024 + pk_idx[k]] = ev;
-                    if (col < wd && prow_ok) {
-                        Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
-                        if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
-                    }
-                }
-            } else {
-                const int j0 = (nb - 1) * SB;  // W of the first (possibly partial) panel
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int col = c16 + 16 * k;
-                    wnext[k] = (j0 + col < n) ? W[(int64_t)prow * n + j0 + col] : 0.0f;
-                }
-            }
-#ifdef GANQ_SOLVE_DUP_G  // timing experiment: the P waves run a copy of the G chain (a second MFMA chain per SIMD)
-            if (bG >= 0) {
-                const int ctx = 4 * bG + gw, pl = max(bG + 2, pbase);
-                chain(std::true_type{}, nb - 1, pl, ctx);
-                chain(std::false_type{}, min(nb - 1, pl - 1), bG + 2, ctx);
-                if (acc[0] == 1.2345e33f) ErrPk[lane] = acc[1];
-            }
-#endif
-        } else if (bG >= 0) {
+        if (bG >= 0) {
             // ---- (G) part 1: the panels right of panel bG+1, descending --------------------------------------
             const int j0 = bG * SB;
             const int wd = min(SB, n - j0);
@@ -366,7 +601,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
             if (gtid < SB) Dg[bG & 1][gtid] = make_float2(dpre, 1.0f / dpre);
         }
         __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
-        if (roleG && bG >= 0) {
+        if (bG >= 0) {
             // ---- (G) part 2: the 64 columns of panel bG+1, descending; then publish R ------------------------
             if (bG + 1 <= nb - 1) {
                 const f32x4v* Ap = reinterpret_cast<const f32x4v*>(ErrPk + lane * 4);
@@ -438,12 +673,13 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
         if (rc) return rc;
     }
     ProfScope prof(KID_SOLVE_S, stream);
+    const int fast = opt_get(OPT_SOLVE_VARIANT) == 1 ? 0 : 1;  // GANQ_SOLVE_VARIANT=1: reduction path only (A/B, tests)
     if (mfma_k_ascending()) {
         hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
-                           V, Q_out, Err_out, errt, pbase, rowlist, nactive);
+                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast);
     } else {
         hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
-                           V, Q_out, Err_out, errt, pbase, rowlist, nactive);
+                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast);
     }
     GANQ_LAUNCH_CHECK();
     return 0;
@@ -452,6 +688,15 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
 }  // namespace ganq
 
 using namespace ganq;
+
+#ifdef GANQ_SOLVE_DEBUG
+extern "C" int ganq_debug_solve_counters(unsigned long long* out4) {
+    GANQ_HIP_CHECK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(ganq::g_solve_dbg), 4 * sizeof(unsigned long long)));
+    unsigned long long z[4] = {0, 0, 0, 0};
+    GANQ_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ganq::g_solve_dbg), z, sizeof(z)));
+    return 0;
+}
+#endif
 
 extern "C" size_t ganq_solve_s_workspace_bytes(int64_t m, int64_t n, int V) {
     (void)V;

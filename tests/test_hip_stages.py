@@ -103,6 +103,54 @@ def test_solve_s_ties_and_duplicates(hip, oracle):
     assert not (Q == 5).any() and not (Q == 10).any()
 
 
+@pytest.mark.parametrize("case", ["unsorted", "reversed_midpoints", "signed_zeros", "near_duplicates", "huge_residuals",
+                                  "nan_codebook", "one_value", "descending"])
+def test_solve_s_threshold_path_adversarial_codebooks(hip, oracle, case, lib_options):
+    """the S-solve decides the argmin by per-lane thresholds on the SORTED codebook and falls back to the first-minimum
+    reductions where that is not exact; both must give the oracle's indices on codebooks built to break the shortcut, and
+    the same bits as the reductions alone (GANQ_SOLVE_VARIANT=1)"""
+    m, n, V = 48, 256, 16
+    W, H, L, T0 = synth(m, n, V, 21, corr=0.1)
+    rng = np.random.default_rng(4)
+    if case == "unsorted":
+        T0 = rng.permuted(T0, axis=1)
+    elif case == "reversed_midpoints":
+        # pairs of entries whose mid-point is hit EXACTLY by weights, with the larger value at the smaller index: a tie must
+        # go to the smaller ORIGINAL index, i.e. to the larger value
+        T0 = np.tile(np.array([0.5, 0.25, 0.125, 0.0625, -0.5, -0.25, -0.125, -0.0625, 1.0, 2.0, 3.0, 4.0, -1.0, -2.0, -3.0, -4.0],
+                              dtype=np.float32), (m, 1))
+        W[:, ::3] = 0.375   # mid-point of 0.5 and 0.25
+        W[:, 1::5] = -0.1875
+        L = np.eye(n, dtype=np.float32)  # no residual: eff == w exactly
+    elif case == "signed_zeros":
+        T0[:, 3] = 0.0
+        T0[:, 7] = -0.0
+        T0[:, 11] = 0.0
+        W[:, ::4] = 0.0
+    elif case == "near_duplicates":
+        T0[:, 5] = np.nextafter(T0[:, 4], np.float32(1.0))  # one float apart: no collision-free range -> reductions
+        T0[:, 9] = np.nextafter(np.nextafter(T0[:, 8], np.float32(1.0)), np.float32(1.0))
+    elif case == "huge_residuals":
+        W[::2, -1] = 3.0e6   # the first solved column leaves residuals far outside the codebook's range
+        W[1::4, -2] = -1.0e30
+    elif case == "nan_codebook":
+        T0[3, 6] = np.nan
+        T0[10, 0] = np.nan
+    elif case == "one_value":
+        T0[:] = 0.01
+    elif case == "descending":
+        T0 = np.ascontiguousarray(T0[:, ::-1])
+    outs = []
+    for variant in (0, 1):
+        lib_options(GANQ_SOLVE_VARIANT=variant)
+        outs.append(hip.solve_s(dev(W), dev(L), dev(T0)).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]), f"{case}: threshold path differs from the reductions in {(outs[0] != outs[1]).sum()} indices"
+    if case != "nan_codebook":  # NaN entries: the reference's argmin is not defined by the oracle's strict-< scan alone
+        assert np.array_equal(outs[0], oracle.solve_s(W, L, T0)), case
+    if case == "reversed_midpoints":  # the ties went to the smaller original index (= the value of larger magnitude here)
+        assert (outs[0][:, 3] == 0).all() and (outs[0][:, 1] == 5).all()
+
+
 def test_solve_s_strided_L_and_empty(hip, oracle):
     W, H, L, T0 = synth(16, 96, 16, 10)
     Lbig = torch.zeros(96, 160, device="cuda")
