@@ -24,6 +24,9 @@ namespace ganq {
 
 constexpr int SB = 64;   // panel width (columns)
 constexpr int SR = 16;   // rows per workgroup
+#ifndef GANQ_SOLVE_RING
+#define GANQ_SOLVE_RING 3
+#endif
 constexpr int SOLVE_LDS_PANELS = 28;  // packed Err blocks kept in LDS (28 x 4 KB = 112 KB next to the 46 KB of panel buffers)
 
 template <int CTRL>
@@ -536,11 +539,14 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                 for (int g = 15; g >= 0; --g)
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g >> 2][g & 3], bb[g >> 2][g & 3], acc, 0, 0, 0);
             };
-            f32x4v a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
-            ld(0, a0, b0);
-            ld(1, a1, b1);
+            // GANQ_SOLVE_RING register sets in rotation: the operands of batch k + RING - 1 are requested while batch k is
+            // multiplied (B comes from L2 / the Infinity Cache: the deeper the ring, the more of that latency is covered)
+            constexpr int RING = GANQ_SOLVE_RING;
+            f32x4v a[RING][4], b[RING][4];
+#pragma unroll
+            for (int u = 0; u < RING - 1; ++u) ld(u, a[u], b[u]);
             GANQ_PIN();
-            // one stage = the loads of batch k+2 spread between the 16 MFMAs of batch k
+            // one stage = the loads of a later batch spread between the 16 MFMAs of batch k
             auto stage_sched = [&]() {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -551,19 +557,14 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                     else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (A)
                 }
             };
-            for (int bi = 0; bi < nbat; bi += 3) {  // whole rounds, no exits inside: a plain counted loop
-                ld(bi + 2, a2, b2);
-                mm(a0, b0);
-                stage_sched();
-                GANQ_PIN();
-                ld(bi + 3, a0, b0);
-                mm(a1, b1);
-                stage_sched();
-                GANQ_PIN();
-                ld(bi + 4, a1, b1);
-                mm(a2, b2);
-                stage_sched();
-                GANQ_PIN();
+            for (int bi = 0; bi < nbat; bi += RING) {  // whole rounds, no exits inside: a plain counted loop
+#pragma unroll
+                for (int u = 0; u < RING; ++u) {
+                    ld(bi + u + RING - 1, a[(u + RING - 1) % RING], b[(u + RING - 1) % RING]);
+                    mm(a[u], b[u]);
+                    stage_sched();
+                    GANQ_PIN();
+                }
             }
         };
         if (bG >= 0) {
