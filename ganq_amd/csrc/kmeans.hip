@@ -148,6 +148,15 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
                                // 3 -> 20.6, 4 -> 19.4, 6 -> 17.7, 8 -> 17.1, 12 -> 16.9, 16 -> 17.3: the independent cost
                                // evaluations of one node overlap, a queued range costs a pass over the queue)
 #endif
+#ifndef KB_CAP_1
+#define KB_CAP_1 12            // ... of the level hs = 1 (measured, 4096x4096: 12 -> 17.0 ms, 4 -> 17.6, 3 -> 18.7, 2 -> 20.6)
+#endif
+#ifndef KB_CAP_2
+#define KB_CAP_2 12            // hs = 2
+#endif
+#ifndef KB_CAP_4
+#define KB_CAP_4 12            // hs = 4
+#endif
 struct KmQueue {               // LDS scratch of the balanced levels: `cap` queued ranges per level (more: finished in place)
     unsigned int* count;
     unsigned long long* seedc;              // best of the node's own first KB_CAP candidates
@@ -174,6 +183,10 @@ __device__ __forceinline__ KmQueue km_queue_at(char* base, int cap) {
 // neighbour's longer loop; what is left of a range is queued.  Pass B: the queued ranges are dealt to 32 groups of 32
 // lanes, 32 candidates per step, (cost, leftmost j) reduced inside the group.  The minimum with its tie-break is
 // order-independent, so who scans what does not change the result.
+// CAP = candidates every node evaluates itself; a compile-time parameter per level (KB_CAP_1 / _2 / _4 for the last three
+// levels).  Smaller caps on the last levels -- whose ranges one would expect to be 1-2 candidates long -- were measured and
+// lose: more ranges end up in the queue pass (defaults stay at 12 everywhere).
+template <int CAP>
 __device__ __forceinline__ void km_level_balanced(const double* cw, const double* cwx, const double* cwxx, const double* dprev,
                                                   uint16_t* acur, double* dcur, int* ag, int cnt, int hs, int n, const KmQueue& q) {
     const int tid = threadIdx.x;
@@ -186,23 +199,23 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
         double bc = INFINITY;
         int bj = 0x7fffffff;
 #pragma unroll
-        for (int c = 0; c < KB_CAP; ++c) {
+        for (int c = 0; c < CAP; ++c) {
             const int j = min(lo + c, hi);  // past the range: the last candidate again (same cost, same j: no effect)
             km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
         }
-        const int rest = hi - (lo + KB_CAP - 1);
+        const int rest = hi - (lo + CAP - 1);
         bool queued = false;
         if (rest > 0) {
             const unsigned int idx = atomicAdd(q.count, 1u);
             if (idx < (unsigned int)q.cap) {
                 q.t[idx] = (unsigned short)t;
-                q.jstart[idx] = (unsigned short)(lo + KB_CAP);
+                q.jstart[idx] = (unsigned short)(lo + CAP);
                 q.cnt[idx] = (unsigned short)min(rest, 65535);
                 q.seedc[idx] = (unsigned long long)__double_as_longlong(bc);
                 q.seedj[idx] = (unsigned int)bj;
                 queued = true;
             } else {
-                for (int j = lo + KB_CAP; j <= hi; ++j)
+                for (int j = lo + CAP; j <= hi; ++j)
                     km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
             }
         }
@@ -405,7 +418,10 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                 while (G < KL_THREADS && G * 2 * cnt <= KL_THREADS) G <<= 1;
                 const int lg = tid & (G - 1);
                 if (cnt >= 128) {
-                    km_level_balanced(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
+                    if (hs == 1) km_level_balanced<KB_CAP_1>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
+                    else if (hs == 2) km_level_balanced<KB_CAP_2>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
+                    else if (hs == 4) km_level_balanced<KB_CAP_4>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
+                    else km_level_balanced<KB_CAP>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
                 } else if (G <= 64) {
                     km_level_nodes(cw, cwx, cwxx, dprev, 0, cw, cwx, cwxx, acur, dcur, ag, 0, cnt - 1, hs, n, G);
                     km_lds_barrier();

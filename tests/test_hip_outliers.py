@@ -45,7 +45,11 @@ def test_outlier_split_matches_algorithm_2(hip, m, n, ratio):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,m,n,ratio", [(1, 256, 1024, 0.01), (7, 100, 512, 0.1), (64, 4096, 4096, 0.005), (3, 48, 2048, 0.0)])
+@pytest.mark.parametrize("M,m,n,ratio", [(1, 256, 1024, 0.01), (7, 100, 512, 0.1), (64, 4096, 4096, 0.005), (3, 48, 2048, 0.0),
+                                         # decode kernel (M <= 32, out_features >= 1024): the sparse entries are added inside the
+                                         # LUT kernel's launch; 16 / 32 features per workgroup, one / two row tiles
+                                         (1, 4096, 1024, 0.01), (16, 2048, 512, 0.05), (20, 1024, 768, 0.02), (3, 8192, 256, 0.03),
+                                         (1, 1500, 512, 0.0)])
 def test_outlier_matmul_and_fused_forward(hip, dtype, M, m, n, ratio):
     g = torch.Generator().manual_seed(M * 13 + m)
     W = heavy_tailed(m, n, seed=n + M)
@@ -76,6 +80,9 @@ def test_outlier_matmul_and_fused_forward(hip, dtype, M, m, n, ratio):
     y_ref = x.double() @ Wq.T + bias.double()
     tol = (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) * float(y_ref.abs().max()) + 1e-3
     assert (y.double() - y_ref).abs().max() <= tol
+    # the one-call entry (decode sizes: one launch; otherwise sparse product + LUT kernel) against the same reference
+    y2 = hip.lut_linear_outliers(x, qweight, lut, bias, bits, rowptr, cols, vals.to(dtype))
+    assert (y2.double() - y_ref).abs().max() <= tol
 
 
 @pytest.mark.parametrize("act_sort,desc_act", [("asc", True), ("none", False)])
