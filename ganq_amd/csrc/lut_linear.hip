@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NW * 64) void lut_mfma_kernel(const uint16_t* __res
 // added by the same launch: wave w takes the entries j = w (mod 16) of each feature into its accumulators before the
 // reduction, so y = round(LUT part + sparse part + bias) with one rounding, like the two-launch path.
 template <int BITS, int RT, bool BF16, int NT, int KC>
-__global__ __launch_bounds__(1024, (RT == 1 && NT == 1 && BITS != 3) ? 8 : 4) void lut_decode_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+__global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_decode_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                           const uint16_t* __restrict__ lut, const uint16_t* __restrict__ bias,
                                                           const float* __restrict__ addend, const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ ocols, const uint16_t* __restrict__ ovals,
@@ -625,7 +625,11 @@ struct LutCsr {  // sparse outliers of the layer (device pointers; rowptr == nul
 template <int BITS, int RT, bool BF16, int NT>
 static void launch_decode(const uint16_t* xp, const uint32_t* qw, const uint16_t* lp, const uint16_t* bp, const float* addend,
                           const LutCsr& csr, int M, int m, int n, const LutPlan& p, uint16_t* yp, hipStream_t stream) {
-    constexpr int KC = RT == 1 ? 8 : 4;  // groups of 32 columns a wave has in flight (n = 4096: all 8 of its share)
+    // groups of 32 columns a wave has in flight.  16 features per workgroup: 8 (n = 4096: all of its share).  32 features:
+    // 4, which fits 64 registers, so two workgroups share a CU and the 448 workgroups of m = 14336 are resident in one
+    // generation (measured cold, M = 1, 14336 x 4096: 14.6 -> 10.9 us; a double-buffered 4 + 4 loop for 16 features was
+    // slower at 4096 x 4096, 6.6 vs 5.7 us)
+    constexpr int KC = (RT == 1 && NT == 1) ? 8 : 4;
     hipLaunchKernelGGL((lut_decode_kernel<BITS, RT, BF16, NT, KC>), dim3((unsigned)p.ob), dim3(1024), 0, stream, xp, qw, lp, bp, addend,
                        csr.rowptr, csr.cols, csr.vals, M, m, n, p.kb_per_wg, yp);
 }
