@@ -37,6 +37,15 @@ __device__ __forceinline__ void km_better(double& bc, int& bj, double c, int j) 
     }
 }
 
+// the same order for a scan that visits its candidates with increasing j (one lane's share of a range): a later candidate
+// only wins with a strictly smaller cost, so the leftmost minimum stays
+__device__ __forceinline__ void km_better_asc(double& bc, int& bj, double c, int j) {
+    if (c < bc) {
+        bc = c;
+        bj = j;
+    }
+}
+
 // ---- LDS-resident variant (n up to ~4.6k): the prefix sums and D[k-1] live in LDS as four fp64 arrays, the argmins of
 // the current layer as u16, one 1024-thread workgroup per row (persistent).  Same arithmetic, association order and
 // tie-breaks as kmeans_kernel; only where the operands live differs -- the global-memory variant spends its time waiting
@@ -96,7 +105,7 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
             const double ci = icw[i + 1], cxi = icwx[i + 1], cxxi = icwxx[i + 1];
             for (int j = lo + lg; j <= hi; j += G) {
                 const int idx = j - base;
-                km_better(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
+                km_better_asc(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
             }
         }
         for (int off = G >> 1; off > 0; off >>= 1) {
@@ -120,7 +129,7 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
             int j2 = 0x7fffffff;
             for (int j = llo + lane; j <= lhi; j += 64) {
                 const int idx = j - base;
-                km_better(c2, j2, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
+                km_better_asc(c2, j2, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
             }
             for (int off = 32; off > 0; off >>= 1) {
                 const double oc = __shfl_xor(c2, off);
@@ -147,6 +156,14 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
 #define KB_CAP 12              // candidates every node evaluates itself, unrolled (4096x4096, V = 16 on MI355X: 2 -> 23.0 ms,
                                // 3 -> 20.6, 4 -> 19.4, 6 -> 17.7, 8 -> 17.1, 12 -> 16.9, 16 -> 17.3: the independent cost
                                // evaluations of one node overlap, a queued range costs a pass over the queue)
+#endif
+#ifndef KB_MIN_NODES
+#define KB_MIN_NODES 512       // levels with at least this many nodes take the balanced path, the others G lanes per node
+                               // (4096x4096, V = 16: 128 -> 16.0 ms, 256 / 512 -> 15.5, 1024 -> 16.1, 2048 -> 17.2, never -> 18.0)
+#endif
+#ifndef KB_RND
+#define KB_RND 2               // candidates per round of a node's own scan (the rounds stop with the longest range of the wave;
+                               // 17.4 -> 16.0 ms against always KB_CAP candidates; 1 / 4 per round: the same within 1 %)
 #endif
 #ifndef KB_CAP_1
 #define KB_CAP_1 12            // ... of the level hs = 1 (measured, 4096x4096: 12 -> 17.0 ms, 4 -> 17.6, 3 -> 18.7, 2 -> 20.6)
@@ -198,10 +215,17 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
         const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
         double bc = INFINITY;
         int bj = 0x7fffffff;
+        // two candidates per round, and no more rounds than the longest range of this wave needs (hs = 1: 3 candidates on
+        // average, CAP only for the few nodes next to a jump of the argmin)
+        const int need = min(hi - lo + 1, CAP);
 #pragma unroll
-        for (int c = 0; c < CAP; ++c) {
-            const int j = min(lo + c, hi);  // past the range: the last candidate again (same cost, same j: no effect)
-            km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+        for (int c = 0; c < CAP; c += KB_RND) {
+            if (!__any(c < need)) break;  // wave-uniform
+#pragma unroll
+            for (int d = 0; d < KB_RND && c + d < CAP; ++d) {
+                const int j = min(lo + c + d, hi);  // past the range: the last candidate again (same cost: no effect)
+                km_better_asc(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+            }
         }
         const int rest = hi - (lo + CAP - 1);
         bool queued = false;
@@ -216,7 +240,7 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
                 queued = true;
             } else {
                 for (int j = lo + CAP; j <= hi; ++j)
-                    km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+                    km_better_asc(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
             }
         }
         if (!queued) {
@@ -236,7 +260,7 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
         int bj = 0x7fffffff;
         for (int d = l32; d < len; d += 32) {
             const int j = j0 + d;
-            km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+            km_better_asc(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
         }
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) {
@@ -390,7 +414,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                 double bc = INFINITY;
                 int bj = 0x7fffffff;
                 for (int j = tid; j <= i; j += KL_THREADS)
-                    km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+                    km_better_asc(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
                 for (int off = 32; off > 0; off >>= 1) {
                     const double oc = __shfl_xor(bc, off);
                     const int oj = __shfl_xor(bj, off);
@@ -417,7 +441,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                 int G = 1;
                 while (G < KL_THREADS && G * 2 * cnt <= KL_THREADS) G <<= 1;
                 const int lg = tid & (G - 1);
-                if (cnt >= 128) {
+                if (cnt >= KB_MIN_NODES) {
                     if (hs == 1) km_level_balanced<KB_CAP_1>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
                     else if (hs == 2) km_level_balanced<KB_CAP_2>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
                     else if (hs == 4) km_level_balanced<KB_CAP_4>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
@@ -437,7 +461,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                         const int hi = max(lo, min(i, (int)acur[right]));
                         const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
                         for (int j = lo + lg; j <= hi; j += G)
-                            km_better(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+                            km_better_asc(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
                     }
                     for (int off = 32; off > 0; off >>= 1) {
                         const double oc = __shfl_xor(bc, off);
@@ -632,7 +656,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
                     stage(pb, len);
                     __syncthreads();
                     for (int idx = tid; idx < len; idx += KL_THREADS)
-                        km_better(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), pb + idx);
+                        km_better_asc(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), pb + idx);
                     __syncthreads();
                 }
                 for (int off = 32; off > 0; off >>= 1) {
@@ -703,7 +727,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
                             const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
                             for (int j = lo + lg; j <= hi; j += G) {
                                 const int idx = j - base;
-                                km_better(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
+                                km_better_asc(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
                             }
                         }
                         for (int off = 32; off > 0; off >>= 1) {

@@ -306,12 +306,19 @@ __global__ __launch_bounds__(NW * 64) void lut_mfma_kernel(const uint16_t* __res
 // deterministic) and wave 0 writes y.  The sparse outliers of a layer (CSR by output feature, ganq_outlier_ratio) are
 // added by the same launch: wave w takes the entries j = w (mod 16) of each feature into its accumulators before the
 // reduction, so y = round(LUT part + sparse part + bias) with one rounding, like the two-launch path.
-template <int BITS, int RT, bool BF16, int NT, int KC>
+//
+// SPLIT (layers with too few output features to give every CU a workgroup, e.g. 2048 x 8192): blockIdx.y splits
+// in_features once more, ACROSS workgroups.  Wave 0 of each workgroup stores the workgroup's tile as fp32 (device-scope
+// stores, like lut_mfma_kernel), takes a ticket on the feature block's counter, and the last one to arrive sums the
+// partial tiles in split order (deterministic), adds addend / bias and writes y; it leaves the counter 0.
+template <int BITS, int RT, bool BF16, int NT, int KC, bool SPLIT>
 __global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_decode_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                           const uint16_t* __restrict__ lut, const uint16_t* __restrict__ bias,
                                                           const float* __restrict__ addend, const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ ocols, const uint16_t* __restrict__ ovals,
-                                                          int M, int m, int n, int kb_per_wave, uint16_t* __restrict__ y) {
+                                                          int M, int m, int n, int kb_per_wave, int kb_per_wg, int KS,
+                                                          float* __restrict__ partial, int* __restrict__ counters,
+                                                          uint16_t* __restrict__ y) {
     constexpr int V = 1 << BITS;
     constexpr int NW = 16;
     constexpr bool STRADDLE = (8 * BITS) % 16 != 0;  // 3-bit: a lane's 24 bits can span two words
@@ -325,7 +332,9 @@ __global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_deco
     const int col = lane & 15, q = lane >> 4;
     const int o0 = blockIdx.x * (16 * NT);
     const int nkb = n >> 5;
-    const int kb_begin = min(nkb, wv * kb_per_wave), kb_end = min(nkb, kb_begin + kb_per_wave);
+    const int ks = SPLIT ? (int)blockIdx.y : 0;
+    const int wg_begin = SPLIT ? min(nkb, ks * kb_per_wg) : 0, wg_end = SPLIT ? min(nkb, wg_begin + kb_per_wg) : nkb;
+    const int kb_begin = min(wg_end, wg_begin + wv * kb_per_wave), kb_end = min(wg_end, kb_begin + kb_per_wave);
     const int off = 8 * BITS * q, wi = off >> 5, sh = off & 31;
     const int wi2 = STRADDLE ? min(wi + 1, BITS - 1) : wi;
     // features are dealt to (tile, lane) interleaved: tile t of lane `col` is feature o0 + NT col + t, so that the NT words
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_deco
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         o_beg[t] = o_end[t] = 0;
-        if (rowptr) {
+        if (rowptr && ks == 0) {  // the sparse part goes with the first split
             o_beg[t] = rowptr[oc[t]] + wv;
             o_end[t] = rowptr[oc[t] + 1];
         }
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_deco
     }
 
     // sparse part: D[row][feature] += x[row][c_j] * v_j over this wave's entries of the feature (fp32)
-    if (rowptr) {
+    if (rowptr && ks == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             for (int j = o_beg[t]; j < o_end[t]; j += NW) {
@@ -486,6 +495,11 @@ __global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_deco
     }
     __syncthreads();
     if (wv != 0) return;
+    auto finish = [&](float v, int row, int o) {
+        if (addend) v += addend[(int64_t)row * m + o];
+        if (bias) v += BF16 ? __builtin_bit_cast(float, (uint32_t)bias[o] << 16) : (float)__builtin_bit_cast(_Float16, bias[o]);
+        y[(int64_t)row * m + o] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v) : __builtin_bit_cast(uint16_t, (_Float16)v);
+    };
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -497,11 +511,58 @@ __global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_deco
                 for (int w2 = 0; w2 < NW - 1; ++w2) v += red[w2][t][r][i][lane];  // fixed order
                 const int row = 16 * r + 4 * q + i, o = o0 + NT * col + t;
                 if (row < M && o < m) {
-                    if (addend) v += addend[(int64_t)row * m + o];
-                    if (bias) v += BF16 ? __builtin_bit_cast(float, (uint32_t)bias[o] << 16) : (float)__builtin_bit_cast(_Float16, bias[o]);
-                    y[(int64_t)row * m + o] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v) : __builtin_bit_cast(uint16_t, (_Float16)v);
+                    if constexpr (SPLIT)
+                        __hip_atomic_store(&partial[((int64_t)ks * M + row) * m + o], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        finish(v, row, o);
                 }
             }
+    if constexpr (SPLIT) {
+        // only wave 0 is left: its device-scope stores are visible to every XCD once vmcnt reaches 0 (no cache walk),
+        // then the ticket; the last workgroup of the feature block sums the KS tiles in split order
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != KS - 1) return;
+        float s[NT][RT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[t][r][i] = 0.f;
+        for (int k2 = 0; k2 < KS; ++k2) {
+            float v[NT][RT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 16 * r + 4 * q + i, o = o0 + NT * col + t;
+                        v[t][r][i] = (row < M && o < m) ? __hip_atomic_load(&partial[((int64_t)k2 * M + row) * m + o], __ATOMIC_RELAXED,
+                                                                            __HIP_MEMORY_SCOPE_AGENT)
+                                                        : 0.f;
+                    }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[t][r][i] += v[t][r][i];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 16 * r + 4 * q + i, o = o0 + NT * col + t;
+                    if (row < M && o < m) finish(s[t][r][i], row, o);
+                }
+        if (lane == 0) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next call
+    }
 }
 
 template <int BITS>
@@ -559,7 +620,7 @@ constexpr size_t LUT_COUNTER_BYTES = 64 * 1024;
 struct LutPlan {
     bool inwg;  // decode kernel: the 16 waves of a workgroup split in_features among themselves (no exchange through memory)
     int nt;     // decode kernel: 16-feature tiles per workgroup (1: 256 workgroups at m = 4096; 2 from m = 8192)
-    int ob, KS, kb_per_wg;
+    int ob, KS, kb_per_wg, kb_per_wave = 0;
     size_t counter_bytes, bytes;
 };
 static LutPlan lut_plan(int64_t M, int64_t m, int64_t n, int bits) {
@@ -578,10 +639,19 @@ static LutPlan lut_plan(int64_t M, int64_t m, int64_t n, int bits) {
         p.nt = nt_opt > 0 ? (nt_opt >= 2 ? 2 : 1) : ((m + 31) / 32 >= 256 ? 2 : 1);
         if ((m & 1) || M > 16) p.nt = 1;  // the pair loads of the 32-feature variant want an even row pitch; LDS (see launch)
         p.ob = (int)((m + 16 * p.nt - 1) / (16 * p.nt));
-        p.KS = 1;
-        p.kb_per_wg = (nkb + LWK - 1) / LWK;  // per wave
+        // fewer feature blocks than CUs: split in_features across workgroups as well, as long as every wave keeps at least
+        // eight groups of 32 columns -- the exchange of the partial tiles costs ~2 us, so it only pays on long rows
+        // (measured cold, 2048 x 8192: M = 1 7.9 -> 7.4 us, M = 16 12.9 -> 11.0 us with 2 splits, 9.1 / 13.7 us with 4;
+        // 2048 x 2048 and 1024 x 4096 lose with any split).  GANQ_LUT_KS forces the factor.
+        const int ks_opt = (int)opt_get(OPT_LUT_KS);
+        int ks = ks_opt > 0 ? ks_opt : std::min(8, 256 / std::max(1, p.ob));
+        while (ks_opt <= 0 && ks > 1 && nkb < 8 * LWK * ks) ks >>= 1;
+        ks = std::max(1, std::min(ks, nkb));
+        p.kb_per_wg = (nkb + ks - 1) / ks;
+        p.KS = (nkb + p.kb_per_wg - 1) / p.kb_per_wg;
+        p.kb_per_wave = (p.kb_per_wg + LWK - 1) / LWK;
         p.counter_bytes = LUT_COUNTER_BYTES;
-        p.bytes = p.counter_bytes;  // kept non-zero so that callers can reuse one workspace for every shape
+        p.bytes = p.counter_bytes + (p.KS > 1 ? align_up((size_t)p.KS * (size_t)M * (size_t)m * sizeof(float), 256) : 0);
         return p;
     }
     p.ob = (int)((m + LUT_FB - 1) / LUT_FB);
@@ -624,14 +694,20 @@ struct LutCsr {  // sparse outliers of the layer (device pointers; rowptr == nul
 
 template <int BITS, int RT, bool BF16, int NT>
 static void launch_decode(const uint16_t* xp, const uint32_t* qw, const uint16_t* lp, const uint16_t* bp, const float* addend,
-                          const LutCsr& csr, int M, int m, int n, const LutPlan& p, uint16_t* yp, hipStream_t stream) {
+                          const LutCsr& csr, int M, int m, int n, const LutPlan& p, float* partial, int* counters, uint16_t* yp,
+                          hipStream_t stream) {
     // groups of 32 columns a wave has in flight.  16 features per workgroup: 8 (n = 4096: all of its share).  32 features:
     // 4, which fits 64 registers, so two workgroups share a CU and the 448 workgroups of m = 14336 are resident in one
     // generation (measured cold, M = 1, 14336 x 4096: 14.6 -> 10.9 us; a double-buffered 4 + 4 loop for 16 features was
     // slower at 4096 x 4096, 6.6 vs 5.7 us)
     constexpr int KC = (RT == 1 && NT == 1) ? 8 : 4;
-    hipLaunchKernelGGL((lut_decode_kernel<BITS, RT, BF16, NT, KC>), dim3((unsigned)p.ob), dim3(1024), 0, stream, xp, qw, lp, bp, addend,
-                       csr.rowptr, csr.cols, csr.vals, M, m, n, p.kb_per_wg, yp);
+    if (p.KS > 1)
+        hipLaunchKernelGGL((lut_decode_kernel<BITS, RT, BF16, NT, KC, true>), dim3((unsigned)p.ob, (unsigned)p.KS), dim3(1024), 0, stream,
+                           xp, qw, lp, bp, addend, csr.rowptr, csr.cols, csr.vals, M, m, n, p.kb_per_wave, p.kb_per_wg, p.KS, partial,
+                           counters, yp);
+    else
+        hipLaunchKernelGGL((lut_decode_kernel<BITS, RT, BF16, NT, KC, false>), dim3((unsigned)p.ob), dim3(1024), 0, stream, xp, qw, lp, bp,
+                           addend, csr.rowptr, csr.cols, csr.vals, M, m, n, p.kb_per_wave, p.kb_per_wg, 1, partial, counters, yp);
 }
 
 template <int BITS, int RT>
@@ -649,14 +725,14 @@ static int launch_lut_rt(const void* x, const uint32_t* qw, const void* lut, con
             // buffer of two row tiles do not fit the LDS); the plan knows
             if constexpr (RT == 1) {
                 if (p.nt == 2) {
-                    if (dtype == 1) launch_decode<BITS, RT, true, 2>(xp, qw, lp, bp, addend, csr, M, m, n, p, yp, stream);
-                    else launch_decode<BITS, RT, false, 2>(xp, qw, lp, bp, addend, csr, M, m, n, p, yp, stream);
+                    if (dtype == 1) launch_decode<BITS, RT, true, 2>(xp, qw, lp, bp, addend, csr, M, m, n, p, partial, counters, yp, stream);
+                    else launch_decode<BITS, RT, false, 2>(xp, qw, lp, bp, addend, csr, M, m, n, p, partial, counters, yp, stream);
                     GANQ_LAUNCH_CHECK();
                     return 0;
                 }
             }
-            if (dtype == 1) launch_decode<BITS, RT, true, 1>(xp, qw, lp, bp, addend, csr, M, m, n, p, yp, stream);
-            else launch_decode<BITS, RT, false, 1>(xp, qw, lp, bp, addend, csr, M, m, n, p, yp, stream);
+            if (dtype == 1) launch_decode<BITS, RT, true, 1>(xp, qw, lp, bp, addend, csr, M, m, n, p, partial, counters, yp, stream);
+            else launch_decode<BITS, RT, false, 1>(xp, qw, lp, bp, addend, csr, M, m, n, p, partial, counters, yp, stream);
             GANQ_LAUNCH_CHECK();
             return 0;
         }

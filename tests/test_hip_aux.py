@@ -156,7 +156,12 @@ def test_pack_roundtrip_and_layout(hip, bits):
                                               (3, 32, torch.bfloat16, 2048, 1024), (2, 24, torch.float16, 1500, 256),
                                               (4, 1, torch.bfloat16, 8192, 256), (4, 16, torch.float16, 8200, 512),
                                               (3, 5, torch.float16, 8192, 320), (4, 3, torch.float16, 1025, 256),
-                                              (2, 1, torch.float16, 9001, 64), (4, 7, torch.float16, 4096, 14336)])
+                                              (2, 1, torch.float16, 9001, 64), (4, 7, torch.float16, 4096, 14336),
+                                              # decode kernel, fewer feature blocks than CUs: in_features split across
+                                              # workgroups too (2 and 4 ways), partial tiles + ticket
+                                              (4, 1, torch.float16, 2048, 8192), (4, 16, torch.bfloat16, 1024, 4096),
+                                              (3, 20, torch.float16, 1500, 2048), (4, 3, torch.float16, 1025, 8192),
+                                              (2, 1, torch.float16, 2048, 4096)])
 def test_lut_linear_vs_dense(hip, oracle, bits, M, dtype, m, n):
     rng = np.random.default_rng(bits * 100 + M)
     V = 2 ** bits
@@ -182,7 +187,7 @@ def test_lut_linear_repeat_is_bitwise_stable(hip):
     # reduction order is fixed -> many calls, interleaved shapes, identical bits
     rng = np.random.default_rng(7)
     outs = {}
-    cases = [(4, 1, 4096, 4096), (3, 16, 1000, 2048), (4, 40, 300, 8192), (2, 3, 129, 64)]
+    cases = [(4, 1, 4096, 4096), (3, 16, 1000, 2048), (4, 40, 300, 8192), (2, 3, 129, 64), (4, 1, 2048, 8192), (4, 9, 1024, 4096)]
     data = {}
     for bits, M, m, n in cases:
         Q = rng.integers(0, 2 ** bits, size=(m, n), dtype=np.uint8)
@@ -234,6 +239,26 @@ def test_lut_linear_one_workspace_serves_alternating_shapes(hip, with_outliers):
                 y = hip.lut_linear_outliers(x, qw, lut, None, bits, *sparse)
             assert torch.isfinite(y).all()
             assert torch.allclose(y.double(), ref, rtol=2 ** -9, atol=2 ** -9 * float(ref.abs().max()) * 0.05 + 1e-6), (rep, tuple(lut.shape))
+
+
+@pytest.mark.parametrize("ks", [2, 3, 5])
+def test_lut_decode_forced_split_matches_unsplit(hip, lib_options, ks):
+    # the cross-workgroup split of the decode kernel with ragged shares (128 column groups in 3 / 5 parts) against the
+    # unsplit launch: same fp32 partial sums in a different association -> equal to rounding, and stable over repeats
+    rng = np.random.default_rng(ks)
+    m, n, bits = 4096, 4096, 4
+    Q = rng.integers(0, 16, size=(m, n), dtype=np.uint8)
+    lut = torch.from_numpy((0.02 * rng.standard_normal((m, 16))).astype(np.float32)).half().cuda()
+    qw = hip.pack_indices(dev(Q), bits)
+    Wq = torch.gather(lut.float(), 1, torch.from_numpy(Q.astype(np.int64)).cuda())
+    for M in (1, 16, 24):
+        x = torch.from_numpy(rng.standard_normal((M, n)).astype(np.float32)).half().cuda()
+        ref = x.double() @ Wq.double().T
+        lib_options(GANQ_LUT_KS=ks)
+        y = hip.lut_linear(x, qw, lut, None, bits)
+        y2 = hip.lut_linear(x, qw, lut, None, bits)
+        assert torch.equal(y, y2)
+        assert torch.allclose(y.double(), ref, rtol=2 ** -10, atol=2 ** -10 * float(ref.abs().max()) * 0.05 + 1e-6), (ks, M)
 
 
 def test_lut_linear_golden_forward(hip):

@@ -49,7 +49,9 @@ def test_outlier_split_matches_algorithm_2(hip, m, n, ratio):
                                          # decode kernel (M <= 32, out_features >= 1024): the sparse entries are added inside the
                                          # LUT kernel's launch; 16 / 32 features per workgroup, one / two row tiles
                                          (1, 4096, 1024, 0.01), (16, 2048, 512, 0.05), (20, 1024, 768, 0.02), (3, 8192, 256, 0.03),
-                                         (1, 1500, 512, 0.0)])
+                                         (1, 1500, 512, 0.0),
+                                         # ... and with in_features split across workgroups (the sparse part goes with split 0)
+                                         (1, 2048, 8192, 0.01), (16, 1024, 4096, 0.02)])
 def test_outlier_matmul_and_fused_forward(hip, dtype, M, m, n, ratio):
     g = torch.Generator().manual_seed(M * 13 + m)
     W = heavy_tailed(m, n, seed=n + M)

@@ -74,6 +74,12 @@ if __name__ == "__main__":
             for (m, n, M) in [(4096, 4096, 1), (4096, 4096, 16), (14336, 4096, 1), (14336, 4096, 16), (2048, 8192, 16)]:
                 print("nt", nt, bench(m, n, 4, M, True))
         sys.exit(0)
+    if "--ks" in sys.argv:  # developer: cross-workgroup split factor of the decode kernel on the layers with few feature blocks
+        for ks in (1, 2, 4, 8):
+            _lib.debug_option("GANQ_LUT_KS", ks)
+            for (m, n, M) in [(2048, 8192, 1), (2048, 8192, 16), (2048, 2048, 1), (2048, 2048, 16), (1024, 4096, 1), (512, 2048, 1)]:
+                print("ks", ks, bench(m, n, 4, M, True))
+        sys.exit(0)
     rows = []
     for (m, n) in [(4096, 4096), (14336, 4096), (4096, 14336), (2048, 2048), (8192, 2048), (2048, 8192)]:
         for M in (1, 16):
