@@ -186,8 +186,19 @@ def lut_forward_report():
     for (m, n, M, cold) in [(4096, 4096, 1, False), (4096, 4096, 1, True), (14336, 4096, 1, True), (4096, 14336, 1, True),
                             (4096, 4096, 16, True)]:
         rows.append(bl.bench(m, n, 4, M, cold))
+    # BASELINE configs[2]: the seven linears of one Llama-3.2-1B decoder layer at decode (M = 1), cold
+    layer = {"q_proj": (2048, 2048), "k_proj": (512, 2048), "v_proj": (512, 2048), "o_proj": (2048, 2048),
+             "gate_proj": (8192, 2048), "up_proj": (8192, 2048), "down_proj": (2048, 8192)}
+    per_shape = {}
+    for shape in sorted(set(layer.values())):
+        per_shape[shape] = bl.bench(shape[0], shape[1], 4, 1, True)
+        rows.append(per_shape[shape])
+    lut_us = sum(per_shape[s]["lut_us"] for s in layer.values())
+    f16_us = sum(per_shape[s]["torch_fp16_us"] for s in layer.values())
     return {"what": "y = x @ dequant(qweight, lut)^T, 4-bit, fp16 activations; device us per call from HIP-graph replays of 200 calls; "
-                    "cold = a ring of layers larger than the 256 MB Infinity Cache", "peak_GBs": HBM_PEAK_GBS, "shapes": rows}
+                    "cold = a ring of layers larger than the 256 MB Infinity Cache", "peak_GBs": HBM_PEAK_GBS, "shapes": rows,
+            "llama32_1b_decoder_layer_M1_cold": {"linears": 7, "lut_us": round(lut_us, 2), "torch_fp16_us": round(f16_us, 2),
+                                                 "speedup": round(f16_us / lut_us, 2)}}
 
 
 def executed_rows(cap, args):

@@ -22,12 +22,27 @@
 
 namespace ganq {
 
-constexpr int SB = 64;   // panel width (columns)
+#ifndef GANQ_SOLVE_SB
+#define GANQ_SOLVE_SB 64
+#endif
+constexpr int SB = GANQ_SOLVE_SB;  // panel width (columns): 64, or 48 (three 16-column tiles: the residual chain on three SIMDs,
+                                   // the column steps alone on the fourth -- see solve_s_kernel)
+static_assert(SB == 64 || SB == 48, "panel width");
+constexpr int SKR = SB / 16;       // 16-column tiles per panel = panel columns per lane of (P) = chain waves of (G)
+constexpr int SKG = SB / 4;        // k-groups (MFMAs) per source panel
+constexpr int SBLK = SB * 16;      // floats per packed operand block
+constexpr int SBLKB = SBLK * 4;    // ... bytes
+constexpr bool SPLIT = SB == 48;   // the two roles on separate SIMDs
+#ifndef GANQ_SOLVE_PREFETCH
+#define GANQ_SOLVE_PREFETCH 1
+#endif
+constexpr bool SOLVE_PF = GANQ_SOLVE_PREFETCH != 0 && !SPLIT;  // a ninth wave that pulls the next step's blocks of L into L2
+constexpr int SOLVE_THREADS = SPLIT ? 13 * 64 : (SOLVE_PF ? 576 : 512);
 constexpr int SR = 16;   // rows per workgroup
 #ifndef GANQ_SOLVE_RING
 #define GANQ_SOLVE_RING 3
 #endif
-constexpr int SOLVE_LDS_PANELS = 28;  // packed Err blocks kept in LDS (28 x 4 KB = 112 KB next to the 46 KB of panel buffers)
+constexpr int SOLVE_LDS_PANELS = SB == 64 ? 28 : 37;  // packed Err blocks kept in LDS (28 x 4 KB / 37 x 3 KB = 112 KB next to the panel buffers)
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t x) {
@@ -65,10 +80,10 @@ __device__ __forceinline__ uint32_t sel_own(uint32_t old, uint32_t nw) {
 }
 
 struct PanelState {
-    float r[4];     // running residual sums of this lane's 4 panel columns (c16 + 16k)
-    float w[4];     // W[row][j0 + c16 + 16k]
-    float e[4];     // err captured at this lane's columns
-    uint32_t q[4];  // index captured at this lane's columns
+    float r[SKR];     // running residual sums of this lane's panel columns (c16 + 16k)
+    float w[SKR];     // W[row][j0 + c16 + 16k]
+    float e[SKR];     // err captured at this lane's columns
+    uint32_t q[SKR];  // index captured at this lane's columns
     float tv;       // T[row][c16] (+inf beyond V)
     uint32_t c16;
 };
@@ -90,6 +105,17 @@ struct PanelState {
 typedef uint32_t __attribute__((address_space(3))) lds_u32_t;
 typedef uint8_t __attribute__((address_space(3))) lds_u8_t;
 
+#ifdef GANQ_SOLVE_TRACE
+// developer timeline: s_memtime stamps of workgroup GANQ_SOLVE_TRACE_WG, wave 0 (role P) and wave 4 (role G), per step
+__device__ unsigned long long g_solve_trace[2][320][6];
+#define GANQ_TRACE(role, s, k) do { if (blockIdx.x == GANQ_SOLVE_TRACE_WG && lane == 0 && gw == 0 && (s) < 320) \
+        g_solve_trace[role][s][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef GANQ_SOLVE_TRACE_WG
+#define GANQ_SOLVE_TRACE_WG 0
+#endif
+#else
+#define GANQ_TRACE(role, s, k) do {} while (0)
+#endif
 #ifdef GANQ_SOLVE_DEBUG
 __device__ unsigned long long g_solve_dbg[4];  // [0] panels on the fast path, [1] panels redone, [2] waves without fast path
 #endif
@@ -227,7 +253,7 @@ __device__ __forceinline__ void panel_step_fast(PanelState& st, const FastRow& f
     st.r[0] = fmaf(err, lrow.x, st.r[0]);
     st.r[1] = fmaf(err, lrow.y, st.r[1]);
     st.r[2] = fmaf(err, lrow.z, st.r[2]);
-    st.r[3] = fmaf(err, lrow.w, st.r[3]);
+    if constexpr (SKR > 3) st.r[SKR - 1] = fmaf(err, lrow.w, st.r[SKR - 1]);
     nsel += sel ? 1u : 0u;
     // the selected lane files the ORIGINAL index of its value; the others write a dummy byte (no exec-mask change)
     *reinterpret_cast<lds_u8_t*>((uintptr_t)(sel ? qaddr + JJ : qdummy)) = (uint8_t)fr.orig;
@@ -274,7 +300,7 @@ __device__ __forceinline__ void panel_step(PanelState& st, const float2 dg, cons
     st.r[0] = fmaf(err, lrow.x, st.r[0]);
     st.r[1] = fmaf(err, lrow.y, st.r[1]);
     st.r[2] = fmaf(err, lrow.z, st.r[2]);
-    st.r[3] = fmaf(err, lrow.w, st.r[3]);
+    if constexpr (SKR > 3) st.r[SKR - 1] = fmaf(err, lrow.w, st.r[SKR - 1]);
     st.q[KREG] = sel_own<OWN>(st.q[KREG], idx);
     st.e[KREG] = __builtin_bit_cast(float, sel_own<OWN>(__builtin_bit_cast(uint32_t, st.e[KREG]), __builtin_bit_cast(uint32_t, err)));
 }
@@ -319,26 +345,34 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // u = 64 p + 4 g + kslot(ksub).  A block stores those 16 values of a lane contiguously:
 //     block[(g >> 2) * 256 + lane * 4 + (g & 3)]   (1024 floats = 4 KB; each of the four 16-byte loads of a wave reads
 //                                                   1 KB contiguously, and LDS reads of it are bank-conflict free)
-//   B blocks (L):   Lr[(p * NT + ct) * 1024 + ..] = L[u][16 ct + c16]     built once per L by l_pack_kernel
+//   B blocks (L):   Lr[lr_block(ct, p) * SBLK + ..] = L[u][16 ct + c16]   built once per L by l_pack_kernel
 //   A blocks (Err): ErrT[tile][p * 1024 + ..]     = Err[row c16][u]      written by the P waves
 // so a batch of 16 MFMAs costs 4 + 4 sixteen-byte loads instead of 16 + 16 dword loads: the lone G wave of a SIMD
 // shares its issue slots with the P wave, and every instruction saved there is matrix-core time gained.
+// block of (output tile ct, source panel p) inside the packed L.  Tile-major: the blocks one chain reads one after the other
+// (p descending, ct fixed) are neighbours in memory -- one sequential stream per wave instead of a stride of NT blocks
+#ifndef GANQ_LR_PANEL_MAJOR
+__host__ __device__ __forceinline__ int64_t lr_block(int ct, int p, int NT, int nb) { (void)NT; return (int64_t)ct * nb + p; }
+#else
+__host__ __device__ __forceinline__ int64_t lr_block(int ct, int p, int NT, int nb) { (void)nb; return (int64_t)p * NT + ct; }
+#endif
+
 __global__ __launch_bounds__(64) void l_pack_kernel(const float* __restrict__ L, int64_t ldl, int n, int NT, bool kasc,
                                                     float* __restrict__ Lr) {
     const int ct = blockIdx.x, p = blockIdx.y;
-    if (4 * p <= ct - (ct & 3)) return;  // only source panels strictly right of the tile's panel are ever read
+    if (p <= ct / SKR) return;  // only source panels strictly right of the tile's panel are ever read
     const int lane = threadIdx.x, c16 = lane & 15, ksub = lane >> 4;
     const int kslot = kasc ? (3 - ksub) : ksub;
     const int col = 16 * ct + c16;
-    f32x4v out[4];
+    f32x4v out[SKR];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int u = 64 * p + 4 * g + kslot;
+    for (int g = 0; g < SKG; ++g) {
+        const int u = SB * p + 4 * g + kslot;
         out[g >> 2][g & 3] = (u < n && col < n) ? L[(int64_t)u * ldl + col] : 0.0f;
     }
-    f32x4v* dst = reinterpret_cast<f32x4v*>(Lr + ((int64_t)p * NT + ct) * 1024 + lane * 4);
+    f32x4v* dst = reinterpret_cast<f32x4v*>(Lr + lr_block(ct, p, NT, (int)gridDim.y) * SBLK + lane * 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dst[j * 64] = out[j];
+    for (int j = 0; j < SKR; ++j) dst[j * 64] = out[j];
 }
 
 // Two roles per workgroup (8 waves, one of each role per SIMD):
@@ -349,7 +383,7 @@ __global__ __launch_bounds__(64) void l_pack_kernel(const float* __restrict__ L,
 //   in descending order -- only who computes when has changed.  G also stages the next panel's triangle of L and
 //   its diagonal (double-buffered), P prefetches its next W columns.
 template <bool KASC>
-__global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ W, const float* __restrict__ L,
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __restrict__ W, const float* __restrict__ L,
                                                       int64_t ldl, const float* __restrict__ Lr, int NT,
                                                       const float* __restrict__ T, int m, int n, int V,
                                                       uint8_t* __restrict__ Q, float* __restrict__ ErrOut,
@@ -358,7 +392,9 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
     __shared__ float4 Ld[2][SB][16];      // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
     __shared__ float Rp[2][SR][SB + 4];   // residual panel handed from (G) to (P)
     __shared__ float2 Dg[2][SB];          // {L[j][j], 1 / L[j][j]} of the panel's columns
-    __shared__ __align__(16) float ErrPk[1024];  // packed Err block of the panel just solved (zero beyond its width)
+    __shared__ __align__(16) float ErrPk[SBLK];  // packed Err block of the panel just solved (zero beyond its width)
+    __shared__ __align__(16) float Bp2[SPLIT ? SKR * SBLK : 4];  // split layout: the B operands of part 2 (packed L blocks of source
+                                                               // panel bG+1, one per tile), staged by (P)
     __shared__ uint8_t Qst[4][4][SB];            // fast path: original index filed by the selected lane, per (P wave, row, step)
     __shared__ uint32_t Qdm[4][64];              // ... and where the lanes that were NOT selected put theirs: one dword slot per
                                                  // lane (60 lanes storing to ONE address would serialise in the LDS)
@@ -367,9 +403,82 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool roleG = wv >= 4;
-    const int gw = wv & 3;
-    const int gtid = tid & 255;  // thread index inside the role
+    bool roleG;
+    int gw;  // index of the wave inside its role
+    if constexpr (SPLIT) {
+        // 13 waves are launched so that, with the hardware dealing consecutive waves to the four SIMDs in turn, one SIMD
+        // holds four of them: those run (P), one wave on each of the other three SIMDs runs the chain of one 16-column
+        // tile (G), the rest leave at once.  The fp32 matrix-core instructions and the fp32 / DPP vector instructions of
+        // (P) execute on the same lanes of a SIMD and do not overlap (measured: a column step takes 3.4 times as long
+        // while a chain runs beside it, and the chain twice as long); apart, each role runs at the speed it has alone.
+        // Where a wave really sits is read from HW_ID, so the result never depends on the dealing order -- an unexpected
+        // order only costs the separation.
+        __shared__ int s_simd[16];
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (lane == 0) s_simd[wv] = (int)((hwid >> 4) & 3u);
+        __syncthreads();
+        const int nw = (int)(blockDim.x >> 6);
+        const int ps = s_simd[0];
+        int np = 0, my_p = -1, ng = 0, my_g = -1;
+        unsigned seen = 1u << ps;
+        for (int w = 0; w < nw; ++w) {
+            const int sd = s_simd[w];
+            if (sd == ps) {
+                if (w == wv) my_p = np;
+                ++np;
+            } else if (!((seen >> sd) & 1u)) {
+                seen |= 1u << sd;
+                if (w == wv) my_g = ng;
+                ++ng;
+            }
+        }
+        if (np < 4 || ng < SKR) {  // not the expected dealing: roles by wave index (uniform over the workgroup)
+            my_p = wv < 4 ? wv : -1;
+            my_g = (wv >= 4 && wv < 4 + SKR) ? wv - 4 : -1;
+        }
+        if (my_p >= 4) my_p = -1;
+        if (my_p < 0 && my_g < 0) return;  // the waves nobody needs: gone before the first barrier of the loops
+        my_p = __builtin_amdgcn_readfirstlane(my_p);  // wave-uniform by construction: keep them in scalar registers
+        my_g = __builtin_amdgcn_readfirstlane(my_g);
+        roleG = my_g >= 0;
+        gw = roleG ? my_g : my_p;
+    } else {
+        roleG = wv >= 4;
+        gw = wv & 3;
+    }
+    const int gtid = gw * 64 + lane;  // thread index inside the role
+    if (SOLVE_PF && wv == 8) {
+        if (!(opt_fast & 2)) return;  // not asked for: gone before the first barrier
+        // Prefetch wave.  Every workgroup walks the packed L in the same order at about the same pace, and every block is
+        // read exactly once per workgroup: the first of the 32 workgroups behind one L2 to ask for a block waits for HBM
+        // (the 67 MB do not stay in the Infinity Cache between launches), and the others, in step with it, wait along --
+        // the chain ran at the latency of that miss, not at the rate of the matrix cores.  This wave touches, one step
+        // ahead, the lines the chain waves of its XCD will read in the next step (a tile's blocks are contiguous in the
+        // tile-major layout; the workgroups of an XCD share the lines out among themselves), and does nothing else.
+        const int nact_ = nactive ? *nactive : m;
+        if ((int)blockIdx.x * SR >= nact_) return;
+        const int nb_ = (n + SB - 1) / SB;
+        const int nwg = (min(nact_, m) + SR - 1) / SR;            // workgroups that run
+        const int xi = (int)blockIdx.x >> 3, nx = (nwg + 7) >> 3;  // this workgroup among those of its XCD (blockIdx % 8)
+        float sink = 0.0f;
+        for (int s_ = 0; s_ <= nb_; ++s_) {
+            const int bn = nb_ - 2 - s_;  // the panel whose chain runs in the NEXT step
+            if (bn >= 0 && bn + 1 <= nb_ - 1) {
+                const int64_t lines = (int64_t)(nb_ - 1 - bn) * (SBLKB / 128);  // 128-byte lines per tile
+                const int64_t per = (lines + nx - 1) / nx, l0 = (int64_t)xi * per, l1 = min(lines, l0 + per);
+#pragma unroll
+                for (int t = 0; t < SKR; ++t) {
+                    const float* base = Lr + lr_block(SKR * bn + t, bn + 1, NT, nb_) * SBLK;
+                    for (int64_t l = l0 + lane; l < l1; l += 64) sink += base[l * 32];
+                }
+            }
+            __syncthreads();
+            __syncthreads();
+        }
+        if (sink == 1.2345e-30f) ErrT[0] = sink;  // never true: keeps the loads
+        return;
+    }
     const int tile = blockIdx.x;
     const int rsub = lane >> 4;
     const int c16 = lane & 15;
@@ -382,12 +491,12 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
     const bool prow_ok = slot < nact;
     const int prow = rowlist ? rowlist[min(slot, nact - 1)] : min(slot, m - 1);
     const int nb = (n + SB - 1) / SB;
-    float* __restrict__ errt = ErrT + (int64_t)tile * nb * 1024;
+    float* __restrict__ errt = ErrT + (int64_t)tile * nb * SBLK;
 
     PanelState st;
     st.c16 = (uint32_t)c16;
     st.tv = (c16 < V) ? T[(int64_t)prow * V + c16] : __builtin_inff();
-    float wnext[4] = {0.f, 0.f, 0.f, 0.f};
+    float wnext[SKR] = {};
     // (P) threshold form of the argmin: sorted codebook, exact switch-over points (see FastRow); ErrPk is free until the
     // first panel has been solved and serves as the sort's scratch (32 dwords per 16-lane row)
     FastRow fr = {};
@@ -395,16 +504,16 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
     if (!roleG) {
         fr = fast_row_setup(st.tv, (uint32_t)c16,
                             reinterpret_cast<volatile lds_u32_t*>((lds_u32_t*)(uintptr_t)(uint32_t)(uintptr_t)ErrPk) + 32 * (4 * gw + rsub));
-        fast_ok = __ballot(fr.xb > 0.0f) == ~0ull && opt_fast;  // all four rows of the wave
+        fast_ok = __ballot(fr.xb > 0.0f) == ~0ull && (opt_fast & 1);  // all four rows of the wave
     }
     const uint32_t qaddr = (uint32_t)(uintptr_t)&Qst[gw][rsub][0], qdummy = (uint32_t)(uintptr_t)&Qdm[gw][lane];
     lds_u8_t* qstage = (lds_u8_t*)(uintptr_t)qaddr;
 
     // (P) where this lane's four Err values go inside a packed block: column col = c16 + 16 k is k-group col >> 2,
     // slot col & 3, i.e. MFMA lane (ksub, row)
-    int pk_idx[4];
+    int pk_idx[SKR];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SKR; ++k) {
         const int col = c16 + 16 * k;
         const int ks = col & 3, ksub_w = KASC ? (3 - ks) : ks;
         const int g = col >> 2;
@@ -417,12 +526,50 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
     if (!roleG) {
         for (int s = 0; s <= nb; ++s) {
             const int bP = nb - s;  // panel solved in this step (none at s = 0)
+            GANQ_TRACE(0, s, 0);
+            // split layout: what the next panel (bP - 1) needs -- its triangle of L, its diagonal, the part-2 operands of its
+            // three tiles -- is fetched and filed here, before the column steps (the buffers are free since the last barrier;
+            // holding the values in registers across the unrolled steps instead costs more registers than the role has)
+            const int bN = bP - 1;
+            if (SPLIT && bN >= 0) {
+                constexpr int NST = (SB * SB) / 256, NB2 = (SKR * SBLK) / 256;
+                static_assert(!SPLIT || ((SB * SB) % 256 == 0 && (SKR * SBLK) % 256 == 0), "staging shares");
+                float lst[NST], bst[NB2], dst_d = 1.0f;
+                const int j0n = bN * SB, wdn = min(SB, n - j0n);
+#pragma unroll
+                for (int e = 0; e < NST; ++e) {
+                    const int idx = e * 256 + gtid;
+                    const int jj = idx / SB, col = idx % SB;
+                    lst[e] = (jj < wdn && col < wdn) ? L[(int64_t)(j0n + jj) * ldl + j0n + col] : 0.0f;
+                }
+                if (gtid < SB && gtid < wdn) dst_d = L[(int64_t)(j0n + gtid) * ldl + j0n + gtid];
+                const bool part2 = bP <= nb - 1;
+                if (part2) {
+#pragma unroll
+                    for (int e = 0; e < NB2; ++e) {
+                        const int idx = e * 256 + gtid;
+                        bst[e] = Lr[lr_block(SKR * bN + idx / SBLK, bP, NT, nb) * SBLK + idx % SBLK];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NST; ++e) {
+                    const int idx = e * 256 + gtid;
+                    const int jj = idx / SB, col = idx % SB;
+                    reinterpret_cast<float*>(&Ld[bN & 1][jj][col & 15])[col >> 4] = lst[e];
+                }
+                if (gtid < SB) Dg[bN & 1][gtid] = make_float2(dst_d, 1.0f / dst_d);
+                if (part2) {
+#pragma unroll
+                    for (int e = 0; e < NB2; ++e) Bp2[e * 256 + gtid] = bst[e];
+                }
+                GANQ_PIN();
+            }
                 // ---- (P) ---------------------------------------------------------------------------------------
                 if (bP <= nb - 1) {
                     const int j0 = bP * SB;
                     const int wd = min(SB, n - j0);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < SKR; ++k) {
                         st.w[k] = wnext[k];
                         st.q[k] = 0;
                         st.e[k] = 0.0f;
@@ -430,7 +577,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                     }
                     if (bP >= 1) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) wnext[k] = W[(int64_t)prow * n + j0 - SB + c16 + 16 * k];  // full panel
+                        for (int k = 0; k < SKR; ++k) wnext[k] = W[(int64_t)prow * n + j0 - SB + c16 + 16 * k];  // full panel
                     }
 #ifndef GANQ_SOLVE_NO_P  // timing experiment: results are meaningless without the panel steps
                     bool bad = !fast_ok;
@@ -456,7 +603,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) st.q[k] = qstage[c16 + 16 * k];
+                            for (int k = 0; k < SKR; ++k) st.q[k] = qstage[c16 + 16 * k];
                         }
                     }
 #ifdef GANQ_SOLVE_DEBUG
@@ -464,7 +611,7 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
 #endif
                 if (bad) {  // wave-uniform: a step left the range the thresholds are exact in (or the row never had one)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < SKR; ++k) {
                             st.q[k] = 0;
                             st.e[k] = 0.0f;
                             st.r[k] = Rp[bP & 1][prow_in_tile][c16 + 16 * k];
@@ -476,14 +623,15 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                         }
                     }
 #endif
+                    GANQ_TRACE(0, s, 1);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < SKR; ++k) {
                         const int col = c16 + 16 * k;
                         const float ev = (col < wd) ? st.e[k] : 0.0f;  // the (partial) top panel is zero beyond n
                         ErrPk[pk_idx[k]] = ev;
                         // the block lives in LDS (panels >= pbase, never read back from memory) or in the global scratch
-                        if (bP >= pbase) ErrL[(bP - pbase) * 1024 + pk_idx[k]] = ev;
-                        else errt[bP * 1024 + pk_idx[k]] = ev;
+                        if (bP >= pbase) ErrL[(bP - pbase) * SBLK + pk_idx[k]] = ev;
+                        else errt[bP * SBLK + pk_idx[k]] = ev;
                         if (col < wd && prow_ok) {
                             Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
                             if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
@@ -492,20 +640,24 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
                 } else {
                     const int j0 = (nb - 1) * SB;  // W of the first (possibly partial) panel
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < SKR; ++k) {
                         const int col = c16 + 16 * k;
                         wnext[k] = (j0 + col < n) ? W[(int64_t)prow * n + j0 + col] : 0.0f;
                     }
                 }
+            GANQ_TRACE(0, s, 2);
             __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
+            GANQ_TRACE(0, s, 3);
             __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
+            GANQ_TRACE(0, s, 4);
         }
         return;
     }
     for (int s = 0; s <= nb; ++s) {
         const int bG = nb - 1 - s;  // panel whose residual is produced in this step (none at s = nb)
+        GANQ_TRACE(1, s, 0);
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        f32x4v bpre[4];  // (G) packed L block (source panel bG+1, this wave's tile): the B operands of part 2
+        f32x4v bpre[SKR];  // (G) packed L block (source panel bG+1, this wave's tile): the B operands of part 2
         // shared by both roles (the P waves run a chain too when they assist, see below)
         const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0xffffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);
@@ -521,35 +673,38 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
             constexpr bool ALDS = decltype(a_in_lds)::value;
             const int nbat = phi - plo + 1;
             if (nbat <= 0) return;
-            auto ld = [&](int bi, f32x4v (&aa)[4], f32x4v (&bb)[4]) {
+            auto ld = [&](int bi, f32x4v (&aa)[SKR], f32x4v (&bb)[SKR]) {
                 const bool real = bi < nbat;
                 const int ps = phi - min(bi, nbat - 1);  // source panel of the batch
-                const uint32_t sB = (uint32_t)(ps * NT + ct) * 4096u;
+                const uint32_t sB = (uint32_t)lr_block(ct, ps, NT, nb) * (uint32_t)SBLKB;
                 const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
-                const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * 1024 + lane * 4);
+                const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * SBLK + lane * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < SKR; ++j) {
                     bb[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * j, (int)sB, 0));
                     if constexpr (ALDS) aa[j] = Al[j * 64];
-                    else aa[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * j, ps * 4096, 0));
+                    else aa[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * j, ps * SBLKB, 0));
                 }
             };
-            auto mm = [&](const f32x4v (&aa)[4], const f32x4v (&bb)[4]) {
+            auto mm = [&](const f32x4v (&aa)[SKR], const f32x4v (&bb)[SKR]) {
 #pragma unroll
-                for (int g = 15; g >= 0; --g)
+                for (int g = SKG - 1; g >= 0; --g)
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g >> 2][g & 3], bb[g >> 2][g & 3], acc, 0, 0, 0);
             };
             // GANQ_SOLVE_RING register sets in rotation: the operands of batch k + RING - 1 are requested while batch k is
             // multiplied (B comes from L2 / the Infinity Cache: the deeper the ring, the more of that latency is covered)
-            constexpr int RING = GANQ_SOLVE_RING;
-            f32x4v a[RING][4], b[RING][4];
+#ifndef GANQ_SPLIT_RING
+#define GANQ_SPLIT_RING 4
+#endif
+            constexpr int RING = SPLIT ? GANQ_SPLIT_RING : GANQ_SOLVE_RING;
+            f32x4v a[RING][SKR], b[RING][SKR];
 #pragma unroll
             for (int u = 0; u < RING - 1; ++u) ld(u, a[u], b[u]);
             GANQ_PIN();
             // one stage = the loads of a later batch spread between the 16 MFMAs of batch k
             auto stage_sched = [&]() {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < SKR; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (B)
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -571,21 +726,27 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
             // ---- (G) part 1: the panels right of panel bG+1, descending --------------------------------------
             const int j0 = bG * SB;
             const int wd = min(SB, n - j0);
-            const int ct = 4 * bG + gw;  // this wave's 16-wide tile of panel bG
+            const int ct = SKR * bG + gw;  // this wave's 16-wide tile of panel bG
             // prefetches for later in this step: the panel's own block of L, its diagonal, the B operands of part 2
-            float lpre[(SB * SB) / 256];
-#pragma unroll
-            for (int e = 0; e < (SB * SB) / 256; ++e) {
-                const int idx = e * 256 + gtid;
-                const int jj = idx >> 6, col = idx & 63;
-                lpre[e] = (jj < wd && col < wd) ? L[(int64_t)(j0 + jj) * ldl + j0 + col] : 0.0f;
-            }
+            // (split layout: the P waves stage the panel's triangle, its diagonal and the part-2 operands instead -- the
+            // chain waves need their registers for a deeper operand ring, and P has both time and registers to spare)
+            constexpr int GT = 64 * SKR;  // threads of the role
+            constexpr int NLP = SPLIT ? 1 : (SB * SB) / GT;
+            float lpre[NLP];
             float dpre = 1.0f;
-            if (gtid < SB && gtid < wd) dpre = L[(int64_t)(j0 + gtid) * ldl + j0 + gtid];
-            if (bG + 1 <= nb - 1) {
-                const uint32_t sb = (uint32_t)((bG + 1) * NT + ct) * 4096u;
+            if constexpr (!SPLIT) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int e = 0; e < NLP; ++e) {
+                    const int idx = e * GT + gtid;
+                    const int jj = idx / SB, col = idx % SB;
+                    lpre[e] = (jj < wd && col < wd) ? L[(int64_t)(j0 + jj) * ldl + j0 + col] : 0.0f;
+                }
+                if (gtid < SB && gtid < wd) dpre = L[(int64_t)(j0 + gtid) * ldl + j0 + gtid];
+            }
+            if (!SPLIT && bG + 1 <= nb - 1) {
+                const uint32_t sb = (uint32_t)lr_block(ct, bG + 1, NT, nb) * (uint32_t)SBLKB;
+#pragma unroll
+                for (int j = 0; j < SKR; ++j)
                     bpre[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcL, voff + 1024 * j, (int)sb, 0));
             }
             const int plds = max(bG + 2, pbase);  // lowest source panel of this chain whose Err block lives in LDS
@@ -593,30 +754,42 @@ __global__ __launch_bounds__(512) void solve_s_kernel(const float* __restrict__ 
             chain(std::true_type{}, nb - 1, plds, ct);
             chain(std::false_type{}, min(nb - 1, plds - 1), bG + 2, ct);
 #endif
+            GANQ_TRACE(1, s, 1);
+            if constexpr (!SPLIT) {
 #pragma unroll
-            for (int e = 0; e < (SB * SB) / 256; ++e) {
-                const int idx = e * 256 + gtid;
-                const int jj = idx >> 6, col = idx & 63;
-                reinterpret_cast<float*>(&Ld[bG & 1][jj][col & 15])[col >> 4] = lpre[e];
+                for (int e = 0; e < NLP; ++e) {
+                    const int idx = e * GT + gtid;
+                    const int jj = idx / SB, col = idx % SB;
+                    reinterpret_cast<float*>(&Ld[bG & 1][jj][col & 15])[col >> 4] = lpre[e];
+                }
+                if (gtid < SB) Dg[bG & 1][gtid] = make_float2(dpre, 1.0f / dpre);
             }
-            if (gtid < SB) Dg[bG & 1][gtid] = make_float2(dpre, 1.0f / dpre);
         }
+        GANQ_TRACE(1, s, 2);
         __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
+        GANQ_TRACE(1, s, 3);
         if (bG >= 0) {
             // ---- (G) part 2: the 64 columns of panel bG+1, descending; then publish R ------------------------
             if (bG + 1 <= nb - 1) {
                 const f32x4v* Ap = reinterpret_cast<const f32x4v*>(ErrPk + lane * 4);
-                f32x4v ap[4];
+                f32x4v ap[SKR];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ap[j] = Ap[j * 64];
+                for (int j = 0; j < SKR; ++j) ap[j] = Ap[j * 64];
+                if constexpr (SPLIT) {
+                    const f32x4v* Bp = reinterpret_cast<const f32x4v*>(Bp2 + gw * SBLK + lane * 4);
 #pragma unroll
-                for (int g = 15; g >= 0; --g)
+                    for (int j = 0; j < SKR; ++j) bpre[j] = Bp[j * 64];
+                }
+#pragma unroll
+                for (int g = SKG - 1; g >= 0; --g)
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[g >> 2][g & 3], bpre[g >> 2][g & 3], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) Rp[bG & 1][rsub * 4 + r][16 * gw + c16] = acc[r];
         }
+        GANQ_TRACE(1, s, 4);
         __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
+        GANQ_TRACE(1, s, 5);
     }
 }
 
@@ -627,10 +800,10 @@ struct SolveLayout {
 static SolveLayout solve_layout(int64_t m, int64_t n) {
     SolveLayout lo;
     lo.nb = (int)((n + SB - 1) / SB);
-    lo.NT = 4 * lo.nb;
+    lo.NT = SKR * lo.nb;
     const int64_t tiles = (m + SR - 1) / SR;
-    lo.errt_bytes = align_up((size_t)tiles * (size_t)lo.nb * 4096, 256);
-    lo.lr_bytes = align_up((size_t)lo.nb * (size_t)lo.NT * 4096, 256);
+    lo.errt_bytes = align_up((size_t)tiles * (size_t)lo.nb * SBLKB, 256);
+    lo.lr_bytes = align_up((size_t)lo.nb * (size_t)lo.NT * SBLKB, 256);
     lo.total = lo.errt_bytes + lo.lr_bytes;
     return lo;
 }
@@ -641,7 +814,7 @@ static int solve_check(const char* who, int64_t m, int64_t n, int V, int64_t ldl
     if (ldl < n) return fail(-1, "%s: ldl=%lld < n=%lld", who, (long long)ldl, (long long)n);
     // packed L: nb * 4 nb blocks of 4 KB behind 32-bit buffer offsets
     const int64_t nb = (n + SB - 1) / SB;
-    if (nb * 4 * nb * 4096 >= (1ll << 32)) return fail(-1, "%s: n=%lld exceeds the 4 GiB buffer window of the packed L", who, (long long)n);
+    if (nb * SKR * nb * SBLKB >= (1ll << 32)) return fail(-1, "%s: n=%lld exceeds the 4 GiB buffer window of the packed L", who, (long long)n);
     return 0;
 }
 
@@ -667,19 +840,22 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
     const int tiles = (int)((m + SR - 1) / SR);
     // the Err blocks of the top SOLVE_LDS_PANELS panels (the ones every later panel re-reads) stay in LDS
     const int pbase = std::max(0, lo.nb - SOLVE_LDS_PANELS);
-    const size_t smem = (size_t)(lo.nb - pbase) * 4096;
+    const size_t smem = (size_t)(lo.nb - pbase) * SBLKB;
     {
         int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(solve_s_kernel<true>), smem);
         if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(solve_s_kernel<false>), smem);
         if (rc) return rc;
     }
     ProfScope prof(KID_SOLVE_S, stream);
-    const int fast = opt_get(OPT_SOLVE_VARIANT) == 1 ? 0 : 1;  // GANQ_SOLVE_VARIANT=1: reduction path only (A/B, tests)
+    int fast = opt_get(OPT_SOLVE_VARIANT) == 1 ? 0 : 1;  // GANQ_SOLVE_VARIANT=1: reduction path only (A/B, tests)
+    // bit 1: the prefetch wave.  It pays where one workgroup per CU walks a long L (measured: 2048 x 8192 3.26 -> 2.91 ms;
+    // 4096 x 4096 unchanged; with several workgroups per CU, 14336 x 4096, it costs 5 %: they cover each other's misses)
+    if (SOLVE_PF && tiles <= 256 && n > 4096) fast |= 2;
     if (mfma_k_ascending()) {
-        hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
+        hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(SOLVE_THREADS), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
                            V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast);
     } else {
-        hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(512), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
+        hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(SOLVE_THREADS), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
                            V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast);
     }
     GANQ_LAUNCH_CHECK();
@@ -689,6 +865,13 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
 }  // namespace ganq
 
 using namespace ganq;
+
+#ifdef GANQ_SOLVE_TRACE
+extern "C" int ganq_debug_solve_trace(unsigned long long* out) {  // [2][320][6]
+    GANQ_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ganq::g_solve_trace), 2 * 320 * 6 * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
 
 #ifdef GANQ_SOLVE_DEBUG
 extern "C" int ganq_debug_solve_counters(unsigned long long* out4) {

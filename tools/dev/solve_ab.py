@@ -19,6 +19,6 @@ for (m, n) in [(4096, 4096), (8192, 2048), (2048, 2048), (3072, 768), (768, 3072
         for _ in range(5): q = _lib.solve_s(W, L, T0)
         e.record(); torch.cuda.synchronize()
         res[variant] = (s.elapsed_time(e) / 5, q)
-    assert torch.equal(res[0][1], res[1][1])
+    if not os.environ.get("GANQ_AB_NOCHECK"): assert torch.equal(res[0][1], res[1][1])
     print(f"{m}x{n}: thresholds {res[0][0]:.3f} ms, reductions only {res[1][0]:.3f} ms  ({res[1][0] / res[0][0]:.2f}x)")
 _lib.debug_option("GANQ_SOLVE_VARIANT", None)
