@@ -335,6 +335,13 @@ __device__ __forceinline__ void panel_all(PanelState& st, const float4 (*Ld)[16]
 //   its diagonal (double-buffered), P prefetches its next W columns.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef GANQ_MFMA_INPLACE
+#define GANQ_MFMA_INPLACE 1  // measured: 4096 x 4096 1.065 -> 1.039 ms, 2048 x 8192 2.91 -> 2.74 ms
+#endif
+__device__ __forceinline__ void mfma_inplace(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 // keeps a stage of the chain loop where it was written: the memory clobber stops IR-level load motion across stage
 // boundaries, the sched_barrier stops the machine scheduler
 #define GANQ_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -688,8 +695,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             };
             auto mm = [&](const f32x4v (&aa)[SKR], const f32x4v (&bb)[SKR]) {
 #pragma unroll
-                for (int g = SKG - 1; g >= 0; --g)
+                for (int g = SKG - 1; g >= 0; --g) {
+#if GANQ_MFMA_INPLACE
+                    // accumulate IN PLACE: the register allocator otherwise moves the accumulator between registers along
+                    // the chain, and a dependent MFMA whose destination differs from its SrcC loses the back-to-back path
+                    mfma_inplace(acc, aa[g >> 2][g & 3], bb[g >> 2][g & 3]);
+#else
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g >> 2][g & 3], bb[g >> 2][g & 3], acc, 0, 0, 0);
+#endif
+                }
             };
             // GANQ_SOLVE_RING register sets in rotation: the operands of batch k + RING - 1 are requested while batch k is
             // multiplied (B comes from L2 / the Infinity Cache: the deeper the ring, the more of that latency is covered)
@@ -712,6 +726,36 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                     else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (A)
                 }
             };
+#if GANQ_MFMA_INPLACE
+            // the MFMAs are inline assembly (see mm), which the scheduler leaves where it is written together with the loads
+            // around it: the interleaving is spelled out -- after every 4 MFMAs of batch k, one 16-byte piece of B and of A of
+            // batch k + RING - 1
+            auto mm_ld = [&](const f32x4v (&aa)[SKR], const f32x4v (&bb)[SKR], int bi, f32x4v (&an)[SKR], f32x4v (&bn)[SKR]) {
+                const bool real = bi < nbat;
+                const int ps = phi - min(bi, nbat - 1);
+                const uint32_t sB = (uint32_t)lr_block(ct, ps, NT, nb) * (uint32_t)SBLKB;
+                const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
+                const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * SBLK + lane * 4);
+#pragma unroll
+                for (int j = SKR - 1; j >= 0; --j) {
+#pragma unroll
+                    for (int g = 4 * j + 3; g >= 4 * j; --g) mfma_inplace(acc, aa[g >> 2][g & 3], bb[g >> 2][g & 3]);
+                    const int jl = SKR - 1 - j;
+                    bn[jl] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * jl, (int)sB, 0));
+                    if constexpr (ALDS) an[jl] = Al[jl * 64];
+                    else an[jl] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * jl, ps * SBLKB, 0));
+                }
+            };
+            for (int bi = 0; bi < nbat; bi += RING) {  // whole rounds, no exits inside: a plain counted loop
+#pragma unroll
+                for (int u = 0; u < RING; ++u) {
+                    mm_ld(a[u], b[u], bi + u + RING - 1, a[(u + RING - 1) % RING], b[(u + RING - 1) % RING]);
+                    GANQ_PIN();
+                }
+            }
+            (void)mm;
+            (void)stage_sched;
+#else
             for (int bi = 0; bi < nbat; bi += RING) {  // whole rounds, no exits inside: a plain counted loop
 #pragma unroll
                 for (int u = 0; u < RING; ++u) {
@@ -721,6 +765,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                     GANQ_PIN();
                 }
             }
+#endif
         };
         if (bG >= 0) {
             // ---- (G) part 1: the panels right of panel bG+1, descending --------------------------------------
@@ -753,6 +798,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
 #ifndef GANQ_SOLVE_NO_G  // timing experiment: results are meaningless without the residual chain
             chain(std::true_type{}, nb - 1, plds, ct);
             chain(std::false_type{}, min(nb - 1, plds - 1), bG + 2, ct);
+#if GANQ_MFMA_INPLACE
+            // (inline assembly is invisible to the hazard recogniser: let the last MFMA retire before acc is read again)
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
 #endif
             GANQ_TRACE(1, s, 1);
             if constexpr (!SPLIT) {
