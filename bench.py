@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 INT8_MFMA_PEAK_TOPS = 5000.0    # MI355X_MICROARCH.md: i8 MFMA = 2x the bf16 rate per clock, bf16 dense ~2.5 PF
-PMC_FILE = "r02_pmc_traffic.json"   # rocprofv3 --pmc summary of the loop's kernels at HEAD (tools/pmc_collect.sh)
+PMC_FILE = "r02_pmc_traffic_v2.json"   # rocprofv3 --pmc summary of the loop's kernels at HEAD (tools/pmc_collect.sh)
 
 
 def log(*a):
