@@ -42,7 +42,7 @@ constexpr int SR = 16;   // rows per workgroup
 #ifndef GANQ_SOLVE_RING
 #define GANQ_SOLVE_RING 3
 #endif
-constexpr int SOLVE_LDS_PANELS = SB == 64 ? 28 : 37;  // packed Err blocks kept in LDS (28 x 4 KB / 37 x 3 KB = 112 KB next to the panel buffers)
+constexpr int SOLVE_LDS_PANELS = SB == 64 ? 28 : 36;  // packed Err blocks kept in LDS (28 x 4 KB / 37 x 3 KB = 112 KB next to the panel buffers)
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t x) {
@@ -347,6 +347,152 @@ __device__ __forceinline__ void mfma_inplace(f32x4& acc, float a, float b) {
 #define GANQ_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------
+// One-wave form of the column steps (split layout): 16 rows x 4 lanes.  Lane (row, sub) owns the panel columns
+// sub + 4k (k = 0 .. SB/4 - 1) and four entries of the row's SORTED codebook with their thresholds (4 sub + i).  A step is
+// the same arithmetic as panel_step_fast / panel_step -- exact quotient, threshold test or first-minimum argmin, err =
+// w - T[idx], rank-1 update -- with quad_perm broadcasts and 2-stage quad reductions instead of the 16-lane ones, and it
+// serves all 16 rows with one instruction stream (about 35 vector instructions per column step instead of 4 x 22).
+constexpr int P4K = SB / 4;
+struct P4State {
+    float r[P4K];   // running residual sums of this lane's panel columns
+    float tc[P4K];  // T[idx] captured at this lane's columns (err = w - tc, recomputed after the panel)
+    // (the weights W[row][j0 + sub + 4k] stay in LDS, where the helper waves staged them: one read per step, a step ahead)
+};
+struct P4Fast {
+    float tv[4], lo[4], hi[4];
+    uint32_t orig[4];
+};
+__device__ __forceinline__ uint32_t quad_or_u(uint32_t x) {
+    x |= dpp_u<0xB1>(x);
+    x |= dpp_u<0x4E>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t quad_min_u(uint32_t x) {
+    x = min(x, dpp_u<0xB1>(x));
+    x = min(x, dpp_u<0x4E>(x));
+    return x;
+}
+template <int OWN>
+__device__ __forceinline__ uint32_t sel_own4(uint32_t old, uint32_t nw) {  // lanes (l & 3) == OWN take nw
+    const unsigned long long mask = 0x1111111111111111ull << OWN;
+    uint32_t out;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(old), "v"(nw), "s"(mask));
+    return out;
+}
+
+template <int JJ>
+__device__ __forceinline__ void p4_step_fast(P4State& st, const P4Fast& f, const float2 dg, const float wk, const float (&l)[P4K],
+                                             uint32_t qaddr, uint32_t qdummy, uint32_t& nsel) {
+    constexpr int K = JJ >> 2, OWN = JJ & 3;
+    const float q0 = st.r[K] * dg.y;
+    const float qe = fmaf(-q0, dg.x, st.r[K]);
+    const float quo = fmaf(qe, dg.y, q0);
+    const float eff_l = wk + quo;
+    const float eff = dpp_f<OWN * 0x55>(eff_l);  // quad_perm: the owner lane of the quad
+    const float wj = dpp_f<OWN * 0x55>(wk);
+    // the intervals are disjoint: at most one lane of the quad, and one entry in it, selects.  Four INDEPENDENT tests and an
+    // OR tree (a chain of selects through one condition register made the step four times as long)
+    uint32_t tq[4], oq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool sel = __builtin_amdgcn_fmed3f(eff, f.lo[i], f.hi[i]) == eff;
+        tq[i] = sel ? __builtin_bit_cast(uint32_t, f.tv[i]) : 0u;
+        oq[i] = sel ? f.orig[i] : 0u;  // orig holds index + 1: 0 = not selected
+    }
+    const uint32_t t = (tq[0] | tq[1]) | (tq[2] | tq[3]);
+    const uint32_t o = (oq[0] | oq[1]) | (oq[2] | oq[3]);
+    const uint32_t tb = quad_or_u(t);
+    const float err = wj - __builtin_bit_cast(float, tb);
+#pragma unroll
+    for (int k = 0; k <= K; ++k) st.r[k] = fmaf(err, l[k], st.r[k]);
+    const bool any = o != 0u;
+    nsel += any ? 1u : 0u;
+    // (the dummy region has SB bytes per lane: the step's offset is an immediate of the store, not 48 hoisted addresses)
+    reinterpret_cast<lds_u8_t*>((uintptr_t)(any ? qaddr : qdummy))[JJ] = (uint8_t)(o - 1u);
+    st.tc[K] = __builtin_bit_cast(float, sel_own4<OWN>(__builtin_bit_cast(uint32_t, st.tc[K]), tb));
+}
+
+// the reduction form (first minimum of |eff - T[v]| over the ORIGINAL order: lane sub holds entries 4 sub + i)
+template <int JJ>
+__device__ __forceinline__ void p4_step_slow(P4State& st, const float (&To)[4], uint32_t sub, const float2 dg, const float wk,
+                                             const float (&l)[P4K], uint32_t qaddr, uint32_t qdummy) {
+    constexpr int K = JJ >> 2, OWN = JJ & 3;
+    const float q0 = st.r[K] * dg.y;
+    const float qe = fmaf(-q0, dg.x, st.r[K]);
+    const float quo = fmaf(qe, dg.y, q0);
+    const float eff_l = wk + quo;
+    const float eff = dpp_f<OWN * 0x55>(eff_l);
+    const float wj = dpp_f<OWN * 0x55>(wk);
+    uint32_t m = __builtin_bit_cast(uint32_t, eff - To[0]) & 0x7fffffffu, li = 0u;
+    float tl = To[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const uint32_t d = __builtin_bit_cast(uint32_t, eff - To[i]) & 0x7fffffffu;
+        const bool less = d < m;  // strict: the first minimum stays
+        m = less ? d : m;
+        li = less ? (uint32_t)i : li;
+        tl = less ? To[i] : tl;
+    }
+    const uint32_t mq = quad_min_u(m);
+    const uint32_t cand = (m == mq) ? (4u * sub + li) : 255u;
+    const uint32_t idx = quad_min_u(cand);
+    const uint32_t tb = quad_or_u((cand == idx) ? __builtin_bit_cast(uint32_t, tl) : 0u);
+    const float err = wj - __builtin_bit_cast(float, tb);
+#pragma unroll
+    for (int k = 0; k <= K; ++k) st.r[k] = fmaf(err, l[k], st.r[k]);
+    reinterpret_cast<lds_u8_t*>((uintptr_t)(sub == (uint32_t)OWN ? qaddr : qdummy))[JJ] = (uint8_t)idx;  // one lane per row files it
+    st.tc[K] = __builtin_bit_cast(float, sel_own4<OWN>(__builtin_bit_cast(uint32_t, st.tc[K]), tb));
+}
+
+// L[j0 + jj][j0 + sub + 4k], k = 0 .. P4K-1, of the step: three 16-byte reads of the lane's slice of the row
+template <int JJ>
+__device__ __forceinline__ void p4_load_l(const float* ld4, uint32_t sub, float (&l)[P4K]) {
+    constexpr int jj = JJ;
+    const float4* src = reinterpret_cast<const float4*>(ld4 + (jj * 4 + (int)sub) * P4K);
+#pragma unroll
+    for (int v = 0; v <= (JJ >> 2) / 4; ++v) {  // the step updates the columns k <= JJ >> 2 only
+        const float4 x = src[v];
+        l[4 * v] = x.x;
+        l[4 * v + 1] = x.y;
+        l[4 * v + 2] = x.z;
+        l[4 * v + 3] = x.w;
+    }
+}
+
+template <bool FULL, int JJ>
+__device__ __forceinline__ void p4_from_fast(P4State& st, const P4Fast& f, const float* ld4, const float2* Dg, const float* wrow,
+                                             uint32_t sub, int wd, float2 dg, float wk, const float (&l)[P4K], uint32_t qaddr,
+                                             uint32_t qdummy, uint32_t& nsel) {
+    float2 dg_n = dg;
+    float wk_n = wk;
+    float ln[P4K] = {};
+    if constexpr (JJ > 0) {
+        dg_n = Dg[JJ - 1];
+        wk_n = wrow[4 * ((JJ - 1) >> 2)];
+        p4_load_l<JJ - 1>(ld4, sub, ln);
+    }
+    if (FULL || JJ < wd) p4_step_fast<JJ>(st, f, dg, wk, l, qaddr, qdummy, nsel);
+    __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: hoisted operand loads of later steps cost registers the wave lacks
+    if constexpr (JJ > 0) p4_from_fast<FULL, JJ - 1>(st, f, ld4, Dg, wrow, sub, wd, dg_n, wk_n, ln, qaddr, qdummy, nsel);
+}
+template <bool FULL, int JJ>
+__device__ __forceinline__ void p4_from_slow(P4State& st, const float (&To)[4], const float* ld4, const float2* Dg, const float* wrow,
+                                             uint32_t sub, int wd, float2 dg, float wk, const float (&l)[P4K], uint32_t qaddr,
+                                             uint32_t qdummy) {
+    float2 dg_n = dg;
+    float wk_n = wk;
+    float ln[P4K] = {};
+    if constexpr (JJ > 0) {
+        dg_n = Dg[JJ - 1];
+        wk_n = wrow[4 * ((JJ - 1) >> 2)];
+        p4_load_l<JJ - 1>(ld4, sub, ln);
+    }
+    if (FULL || JJ < wd) p4_step_slow<JJ>(st, To, sub, dg, wk, l, qaddr, qdummy);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (JJ > 0) p4_from_slow<FULL, JJ - 1>(st, To, ld4, Dg, wrow, sub, wd, dg_n, wk_n, ln, qaddr, qdummy);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Packed operand blocks.  The chain consumes, per (source panel p of 64 columns, 16-wide output tile), 16 k-groups of
 // 4 columns; lane (ksub = lane >> 4, c16 = lane & 15) of the MFMA needs for k-group g the element with
 // u = 64 p + 4 g + kslot(ksub).  A block stores those 16 values of a lane contiguously:
@@ -396,13 +542,19 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                                                       uint8_t* __restrict__ Q, float* __restrict__ ErrOut,
                                                       float* __restrict__ ErrT, int pbase, const int* __restrict__ rowlist,
                                                       const int* __restrict__ nactive, int opt_fast) {
-    __shared__ float4 Ld[2][SB][16];      // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
+    __shared__ float4 Ld[SPLIT ? 1 : 2][SPLIT ? 1 : SB][16];  // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
+    __shared__ __align__(16) float Ld4[SPLIT ? 2 * SB * SB : 4];  // split layout: [buf][jj][sub][k] <-> L[j0+jj][j0 + sub + 4k]
+    __shared__ float Fs[SPLIT ? 3 : 1][SPLIT ? 16 : 1][16];    // split layout: sorted codebook, lo, hi of the 16 rows (set-up -> P wave)
+    __shared__ uint32_t Fo[SPLIT ? 16 : 1][16];                // ... original indices
+    __shared__ int Fok[16];                                    // ... row can use the thresholds
+    __shared__ float Wp[SPLIT ? 2 : 1][SPLIT ? 16 : 1][SB];    // split layout: W of the next panel's columns, staged by the helper waves
     __shared__ float Rp[2][SR][SB + 4];   // residual panel handed from (G) to (P)
     __shared__ float2 Dg[2][SB];          // {L[j][j], 1 / L[j][j]} of the panel's columns
     __shared__ __align__(16) float ErrPk[SBLK];  // packed Err block of the panel just solved (zero beyond its width)
     __shared__ __align__(16) float Bp2[SPLIT ? SKR * SBLK : 4];  // split layout: the B operands of part 2 (packed L blocks of source
                                                                // panel bG+1, one per tile), staged by (P)
     __shared__ uint8_t Qst[4][4][SB];            // fast path: original index filed by the selected lane, per (P wave, row, step)
+    __shared__ uint8_t Qdm4[SPLIT ? 64 : 1][SPLIT ? SB : 1];  // split layout: the same, SB bytes per lane (offset = step)
     __shared__ uint32_t Qdm[4][64];              // ... and where the lanes that were NOT selected put theirs: one dword slot per
                                                  // lane (60 lanes storing to ONE address would serialise in the LDS)
     extern __shared__ __align__(16) float ErrL[];  // packed Err blocks of the panels >= pbase, the A operand's hot part
@@ -527,6 +679,201 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
         pk_idx[k] = (g >> 2) * 256 + (ksub_w * 16 + prow_in_tile) * 4 + (g & 3);
     }
 
+    if constexpr (SPLIT) {
+        if (roleG) {
+            __syncthreads();  // the set-up barrier of the P side
+        } else {
+            // ---- the SIMD without chains: wave gw = 0 runs the column steps of all 16 rows (4 lanes per row); the other three
+            // waves, after helping with the set-up, stage what the next panel needs -----------------------------------------
+            Fs[0][4 * gw + rsub][c16] = fr.tv;
+            Fs[1][4 * gw + rsub][c16] = fr.lo;
+            Fs[2][4 * gw + rsub][c16] = fr.hi;
+            Fo[4 * gw + rsub][c16] = fr.orig;
+            if (c16 == 0) Fok[4 * gw + rsub] = fr.xb > 0.0f ? 1 : 0;
+            __syncthreads();
+            if (gw != 0) {
+                const int htid = (gw - 1) * 64 + lane;  // 0 .. 191
+                constexpr int HT = 192, NST = (SB * SB) / HT, NB2 = (SKR * SBLK) / HT;
+                static_assert((SB * SB) % HT == 0 && (SKR * SBLK) % HT == 0, "staging shares");
+                // ... and they pull the blocks of L that the chains of this XCD read in the NEXT step into L2, one line per
+                // thread and tile: every block is read once per workgroup, and the 32 workgroups behind an L2 would otherwise
+                // miss together (see the prefetch wave of the 64-column layout)
+                const int nwg = (min(nact, m) + SR - 1) / SR;
+                const int xi = (int)blockIdx.x >> 3, nx = (nwg + 7) >> 3;
+                float sink = 0.0f;
+                for (int s = 0; s <= nb; ++s) {
+                    const int bP = nb - s, bN = bP - 1;  // bN: the panel whose operands are staged in this step
+                    {
+                        const int bn = nb - 2 - s;  // the panel whose chain runs in the next step
+                        if (bn >= 0 && bn + 1 <= nb - 1) {
+                            const int64_t lines = (int64_t)(nb - 1 - bn) * (SBLKB / 128);
+                            const int64_t per = (lines + nx - 1) / nx, l0 = (int64_t)xi * per, l1 = min(lines, l0 + per);
+#pragma unroll
+                            for (int t = 0; t < SKR; ++t) {
+                                const float* base = Lr + lr_block(SKR * bn + t, bn + 1, NT, nb) * SBLK;
+                                for (int64_t l = l0 + htid; l < l1; l += HT) sink += base[l * 32];
+                            }
+                        }
+                    }
+                    if (bN >= 0) {
+                        float lst[NST], bst[NB2], dst_d = 1.0f;
+                        const int j0n = bN * SB, wdn = min(SB, n - j0n);
+#pragma unroll
+                        for (int e = 0; e < NST; ++e) {
+                            const int idx = e * HT + htid;
+                            const int jj = idx / SB, col = idx % SB;
+                            lst[e] = (jj < wdn && col < wdn) ? L[(int64_t)(j0n + jj) * ldl + j0n + col] : 0.0f;
+                        }
+                        if (htid < SB && htid < wdn) dst_d = L[(int64_t)(j0n + htid) * ldl + j0n + htid];
+                        const bool part2 = bP <= nb - 1;
+                        if (part2) {
+#pragma unroll
+                            for (int e = 0; e < NB2; ++e) {
+                                const int idx = e * HT + htid;
+                                bst[e] = Lr[lr_block(SKR * bN + idx / SBLK, bP, NT, nb) * SBLK + idx % SBLK];
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < NST; ++e) {
+                            const int idx = e * HT + htid;
+                            const int jj = idx / SB, col = idx % SB;
+                            Ld4[(bN & 1) * SB * SB + (jj * 4 + (col & 3)) * P4K + (col >> 2)] = lst[e];
+                        }
+                        if (htid < SB) Dg[bN & 1][htid] = make_float2(dst_d, 1.0f / dst_d);
+                        if (part2) {
+#pragma unroll
+                            for (int e = 0; e < NB2; ++e) Bp2[e * HT + htid] = bst[e];
+                        }
+                        // the 16 rows' weights of panel bN (zero beyond n)
+#pragma unroll
+                        for (int e = 0; e < (16 * SB) / HT; ++e) {
+                            const int idx = e * HT + htid;
+                            const int rr = idx / SB, col = idx % SB;
+                            const int sl = tile * SR + rr;
+                            const int pr = rowlist ? rowlist[min(sl, nact - 1)] : min(sl, m - 1);
+                            Wp[bN & 1][rr][col] = (j0n + col < n) ? W[(int64_t)pr * n + j0n + col] : 0.0f;
+                        }
+                    }
+                    __syncthreads();  // panel bP solved: its packed Err block (ErrPk) and its indices (Qst) are in LDS
+                    // The helpers carry the panel's results to memory, so that the P wave never waits for a store: Err block ->
+                    // global scratch (panels the chains read from memory), indices -> Q, errors -> ErrOut.  The stores are only
+                    // waited for at the NEXT step's first barrier (a full __syncthreads): the scratch block is first read two
+                    // steps later.
+                    if (bP <= nb - 1) {
+                        const int j0 = bP * SB, wd = min(SB, n - j0);
+                        if (bP < pbase) {
+                            const float4 v = reinterpret_cast<const float4*>(ErrPk)[htid];  // SBLK = 4 * 192 floats
+                            reinterpret_cast<float4*>(errt + bP * SBLK)[htid] = v;
+                        }
+                        const int rr = htid / (SB / 4), g4 = htid % (SB / 4);  // row, group of four columns
+                        const int sl = tile * SR + rr;
+                        if (sl < nact) {
+                            const int pr = rowlist ? rowlist[sl] : sl;
+                            const uint32_t qq = *reinterpret_cast<const uint32_t*>(&Qst[0][0][0] + rr * SB + 4 * g4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int col = 4 * g4 + c;
+                                if (col < wd) {
+                                    Q[(int64_t)pr * n + j0 + col] = (uint8_t)min((qq >> (8 * c)) & 0xffu, (uint32_t)(V - 1));
+                                    if (ErrOut) {
+                                        const int pk = (g4 >> 2) * 256 + ((KASC ? 3 - c : c) * 16 + rr) * 4 + (g4 & 3);
+                                        ErrOut[(int64_t)pr * n + j0 + col] = ErrPk[pk];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // second barrier: LDS reads done, stores in flight
+                }
+                if (sink == 1.2345e-30f) ErrT[0] = sink;  // never true: keeps the prefetch loads
+                return;
+            }
+            // ---- the P wave ------------------------------------------------------------------------------------------------
+            const int row4 = lane >> 2;
+            const uint32_t sub = (uint32_t)(lane & 3);
+            const int slot4 = tile * SR + row4;
+            const int prow4 = rowlist ? rowlist[min(slot4, nact - 1)] : min(slot4, m - 1);
+            P4Fast pf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * (int)sub + i;
+                pf.tv[i] = Fs[0][row4][e];
+                pf.lo[i] = Fs[1][row4][e];
+                pf.hi[i] = Fs[2][row4][e];
+                pf.orig[i] = Fo[row4][e] + 1u;
+            }
+            const bool fast4 = __ballot(Fok[row4] != 0) == ~0ull && (opt_fast & 1);
+            const uint32_t qaddr4 = (uint32_t)(uintptr_t)&Qst[0][0][0] + (uint32_t)(row4 * SB);
+            const uint32_t qdummy4 = (uint32_t)(uintptr_t)&Qdm4[lane][0];
+            // column sub + 4k is k-group k, slot sub of a packed block: index pk4b + (k >> 2) * 256 + (k & 3)
+            const int pk4b = ((KASC ? (3 - (int)sub) : (int)sub) * 16 + row4) * 4;
+            P4State ps;
+            for (int s = 0; s <= nb; ++s) {
+                const int bP = nb - s;
+                GANQ_TRACE(0, s, 0);
+                if (bP <= nb - 1) {
+                    const int j0 = bP * SB;
+                    const int wd = min(SB, n - j0);
+#pragma unroll
+                    for (int k = 0; k < P4K; ++k) {
+                        ps.tc[k] = 0.0f;
+                        ps.r[k] = Rp[bP & 1][row4][(int)sub + 4 * k];
+                    }
+                    const float* wrow = &Wp[bP & 1][row4][(int)sub];  // this lane's columns: wrow[4k]
+                    const float wk0 = wrow[4 * ((SB - 1) >> 2)];
+                    const float* ld4 = Ld4 + (bP & 1) * SB * SB;
+                    const float2* Dgp = Dg[bP & 1];
+                    float l0[P4K];
+                    p4_load_l<SB - 1>(ld4, sub, l0);
+                    bool bad = !fast4;
+                    if (fast4) {
+                        uint32_t nsel = 0;
+                        if (wd == SB) p4_from_fast<true, SB - 1>(ps, pf, ld4, Dgp, wrow, sub, wd, Dgp[SB - 1], wk0, l0, qaddr4, qdummy4, nsel);
+                        else p4_from_fast<false, SB - 1>(ps, pf, ld4, Dgp, wrow, sub, wd, Dgp[SB - 1], wk0, l0, qaddr4, qdummy4, nsel);
+                        nsel += dpp_u<0xB1>(nsel);
+                        nsel += dpp_u<0x4E>(nsel);
+                        bad = __ballot(nsel != (uint32_t)wd) != 0ull;
+                    }
+#ifdef GANQ_SOLVE_DEBUG
+                    if (lane == 0) atomicAdd(&g_solve_dbg[fast4 ? (bad ? 1 : 0) : 2], 1ull);
+#endif
+                    if (bad) {  // wave-uniform: redo the panel by the reduction form
+#pragma unroll
+                        for (int k = 0; k < P4K; ++k) {
+                            ps.tc[k] = 0.0f;
+                            ps.r[k] = Rp[bP & 1][row4][(int)sub + 4 * k];
+                        }
+                        float To[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int e = 4 * (int)sub + i;
+                            To[i] = (e < V) ? T[(int64_t)prow4 * V + e] : __builtin_inff();
+                        }
+                        if (wd == SB) p4_from_slow<true, SB - 1>(ps, To, ld4, Dgp, wrow, sub, wd, Dgp[SB - 1], wk0, l0, qaddr4, qdummy4);
+                        else p4_from_slow<false, SB - 1>(ps, To, ld4, Dgp, wrow, sub, wd, Dgp[SB - 1], wk0, l0, qaddr4, qdummy4);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the indices filed in LDS by the steps
+                    __builtin_amdgcn_wave_barrier();
+                    GANQ_TRACE(0, s, 1);
+#pragma unroll
+                    for (int k = 0; k < P4K; ++k) {
+                        const int col = (int)sub + 4 * k;
+                        const float ev = (col < wd) ? wrow[4 * k] - ps.tc[k] : 0.0f;  // err = w - T[idx]; zero beyond n in the top panel
+                        const int pk = pk4b + (k >> 2) * 256 + (k & 3);
+                        ErrPk[pk] = ev;  // (the helper waves take it, and the indices in Qst, to memory after the barrier)
+                        if (bP >= pbase) ErrL[(bP - pbase) * SBLK + pk] = ev;
+                    }
+                }
+                GANQ_TRACE(0, s, 2);
+                __syncthreads();
+                GANQ_TRACE(0, s, 3);
+                __syncthreads();
+                GANQ_TRACE(0, s, 4);
+            }
+            return;
+        }
+    }
+
     // The two roles run SEPARATE loops with the same number of barriers (s_barrier counts arrivals, not places): the
     // registers of one role are then not live in the other's loop, and the kernel needs max(P, G) of them instead of
     // the sum.
@@ -534,43 +881,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
         for (int s = 0; s <= nb; ++s) {
             const int bP = nb - s;  // panel solved in this step (none at s = 0)
             GANQ_TRACE(0, s, 0);
-            // split layout: what the next panel (bP - 1) needs -- its triangle of L, its diagonal, the part-2 operands of its
-            // three tiles -- is fetched and filed here, before the column steps (the buffers are free since the last barrier;
-            // holding the values in registers across the unrolled steps instead costs more registers than the role has)
-            const int bN = bP - 1;
-            if (SPLIT && bN >= 0) {
-                constexpr int NST = (SB * SB) / 256, NB2 = (SKR * SBLK) / 256;
-                static_assert(!SPLIT || ((SB * SB) % 256 == 0 && (SKR * SBLK) % 256 == 0), "staging shares");
-                float lst[NST], bst[NB2], dst_d = 1.0f;
-                const int j0n = bN * SB, wdn = min(SB, n - j0n);
-#pragma unroll
-                for (int e = 0; e < NST; ++e) {
-                    const int idx = e * 256 + gtid;
-                    const int jj = idx / SB, col = idx % SB;
-                    lst[e] = (jj < wdn && col < wdn) ? L[(int64_t)(j0n + jj) * ldl + j0n + col] : 0.0f;
-                }
-                if (gtid < SB && gtid < wdn) dst_d = L[(int64_t)(j0n + gtid) * ldl + j0n + gtid];
-                const bool part2 = bP <= nb - 1;
-                if (part2) {
-#pragma unroll
-                    for (int e = 0; e < NB2; ++e) {
-                        const int idx = e * 256 + gtid;
-                        bst[e] = Lr[lr_block(SKR * bN + idx / SBLK, bP, NT, nb) * SBLK + idx % SBLK];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < NST; ++e) {
-                    const int idx = e * 256 + gtid;
-                    const int jj = idx / SB, col = idx % SB;
-                    reinterpret_cast<float*>(&Ld[bN & 1][jj][col & 15])[col >> 4] = lst[e];
-                }
-                if (gtid < SB) Dg[bN & 1][gtid] = make_float2(dst_d, 1.0f / dst_d);
-                if (part2) {
-#pragma unroll
-                    for (int e = 0; e < NB2; ++e) Bp2[e * 256 + gtid] = bst[e];
-                }
-                GANQ_PIN();
-            }
                 // ---- (P) ---------------------------------------------------------------------------------------
                 if (bP <= nb - 1) {
                     const int j0 = bP * SB;
@@ -676,8 +986,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
         // three rotating register sets; every load is unconditional and the loop runs whole rounds of three
         // (batches past the end read B through rsrcZ: zeros leave the accumulator as it is), so that the waits
         // in the steady state count exactly the loads still allowed in flight.
+        // a_in_lds: 1 = every A block of the segment is in LDS, 0 = none, 2 = decided per batch (split layout: ONE segment per
+        // step, so the ring is filled once -- each fill is a full memory round trip before the first MFMA)
         auto chain = [&](auto a_in_lds, int phi, int plo, const int ct) {
-            constexpr bool ALDS = decltype(a_in_lds)::value;
+            constexpr bool ALDS = decltype(a_in_lds)::value == 1;
+            constexpr bool MIXED = decltype(a_in_lds)::value == 2;
             const int nbat = phi - plo + 1;
             if (nbat <= 0) return;
             auto ld = [&](int bi, f32x4v (&aa)[SKR], f32x4v (&bb)[SKR]) {
@@ -689,7 +1002,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
 #pragma unroll
                 for (int j = 0; j < SKR; ++j) {
                     bb[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * j, (int)sB, 0));
-                    if constexpr (ALDS) aa[j] = Al[j * 64];
+                    if (ALDS || (MIXED && ps >= pbase)) aa[j] = Al[j * 64];
                     else aa[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * j, ps * SBLKB, 0));
                 }
             };
@@ -736,13 +1049,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                 const uint32_t sB = (uint32_t)lr_block(ct, ps, NT, nb) * (uint32_t)SBLKB;
                 const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
                 const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * SBLK + lane * 4);
+                const bool a_lds = ALDS || (MIXED && ps >= pbase);  // wave-uniform
 #pragma unroll
                 for (int j = SKR - 1; j >= 0; --j) {
 #pragma unroll
                     for (int g = 4 * j + 3; g >= 4 * j; --g) mfma_inplace(acc, aa[g >> 2][g & 3], bb[g >> 2][g & 3]);
                     const int jl = SKR - 1 - j;
                     bn[jl] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * jl, (int)sB, 0));
-                    if constexpr (ALDS) an[jl] = Al[jl * 64];
+                    if (a_lds) an[jl] = Al[jl * 64];
                     else an[jl] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * jl, ps * SBLKB, 0));
                 }
             };
@@ -796,8 +1110,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             }
             const int plds = max(bG + 2, pbase);  // lowest source panel of this chain whose Err block lives in LDS
 #ifndef GANQ_SOLVE_NO_G  // timing experiment: results are meaningless without the residual chain
-            chain(std::true_type{}, nb - 1, plds, ct);
-            chain(std::false_type{}, min(nb - 1, plds - 1), bG + 2, ct);
+            if constexpr (false) {  // ONE mixed segment per step (A source decided per batch): measured slower, 23.5 vs 17.9 us for
+                (void)plds;         // the last chains -- the per-batch branch costs the ring its load / MFMA interleave
+                chain(std::integral_constant<int, 2>{}, nb - 1, bG + 2, ct);
+            } else {
+                chain(std::integral_constant<int, 1>{}, nb - 1, plds, ct);
+                chain(std::integral_constant<int, 0>{}, min(nb - 1, plds - 1), bG + 2, ct);
+            }
 #if GANQ_MFMA_INPLACE
             // (inline assembly is invisible to the hazard recogniser: let the last MFMA retire before acc is read again)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
