@@ -970,6 +970,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
         }
         return;
     }
+#ifndef GANQ_SPLIT_RING
+#define GANQ_SPLIT_RING 4
+#endif
+#ifndef GANQ_SOLVE_PRIME
+#define GANQ_SOLVE_PRIME 0  // measured: the chains start 0.2-0.5 us earlier and part 2 takes 0.3 us longer -- the chain waves are not
+                            // the critical path of most steps; 4096 x 4096 1.05 vs 1.04 ms.  Off.
+#endif
+    constexpr int RING = SPLIT ? GANQ_SPLIT_RING : GANQ_SOLVE_RING;
+    // the operand ring lives across the steps: the first RING - 1 batches of the NEXT step's chain are requested before this
+    // step's barriers (the blocks they need exist since long), so that a chain starts with its operands at hand instead of a
+    // memory round trip
+    constexpr bool PRIME = GANQ_SOLVE_PRIME != 0 && GANQ_MFMA_INPLACE != 0;
+    f32x4v ra[RING][SKR], rb[RING][SKR];
+    bool primed = false;
     for (int s = 0; s <= nb; ++s) {
         const int bG = nb - 1 - s;  // panel whose residual is produced in this step (none at s = nb)
         GANQ_TRACE(1, s, 0);
@@ -988,11 +1002,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
         // in the steady state count exactly the loads still allowed in flight.
         // a_in_lds: 1 = every A block of the segment is in LDS, 0 = none, 2 = decided per batch (split layout: ONE segment per
         // step, so the ring is filled once -- each fill is a full memory round trip before the first MFMA)
-        auto chain = [&](auto a_in_lds, int phi, int plo, const int ct) {
+        auto chain = [&](auto a_in_lds, int phi, int plo, const int ct, bool have_head) {
             constexpr bool ALDS = decltype(a_in_lds)::value == 1;
             constexpr bool MIXED = decltype(a_in_lds)::value == 2;
             const int nbat = phi - plo + 1;
             if (nbat <= 0) return;
+            auto& a = ra;
+            auto& b = rb;
             auto ld = [&](int bi, f32x4v (&aa)[SKR], f32x4v (&bb)[SKR]) {
                 const bool real = bi < nbat;
                 const int ps = phi - min(bi, nbat - 1);  // source panel of the batch
@@ -1020,13 +1036,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             };
             // GANQ_SOLVE_RING register sets in rotation: the operands of batch k + RING - 1 are requested while batch k is
             // multiplied (B comes from L2 / the Infinity Cache: the deeper the ring, the more of that latency is covered)
-#ifndef GANQ_SPLIT_RING
-#define GANQ_SPLIT_RING 4
-#endif
-            constexpr int RING = SPLIT ? GANQ_SPLIT_RING : GANQ_SOLVE_RING;
-            f32x4v a[RING][SKR], b[RING][SKR];
+            if (!have_head) {  // wave-uniform
 #pragma unroll
-            for (int u = 0; u < RING - 1; ++u) ld(u, a[u], b[u]);
+                for (int u = 0; u < RING - 1; ++u) ld(u, a[u], b[u]);
+            }
             GANQ_PIN();
             // one stage = the loads of a later batch spread between the 16 MFMAs of batch k
             auto stage_sched = [&]() {
@@ -1112,10 +1125,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
 #ifndef GANQ_SOLVE_NO_G  // timing experiment: results are meaningless without the residual chain
             if constexpr (false) {  // ONE mixed segment per step (A source decided per batch): measured slower, 23.5 vs 17.9 us for
                 (void)plds;         // the last chains -- the per-batch branch costs the ring its load / MFMA interleave
-                chain(std::integral_constant<int, 2>{}, nb - 1, bG + 2, ct);
+                chain(std::integral_constant<int, 2>{}, nb - 1, bG + 2, ct, false);
             } else {
-                chain(std::integral_constant<int, 1>{}, nb - 1, plds, ct);
-                chain(std::integral_constant<int, 0>{}, min(nb - 1, plds - 1), bG + 2, ct);
+                chain(std::integral_constant<int, 1>{}, nb - 1, plds, ct, PRIME && primed);
+                chain(std::integral_constant<int, 0>{}, min(nb - 1, plds - 1), bG + 2, ct, false);
             }
 #if GANQ_MFMA_INPLACE
             // (inline assembly is invisible to the hazard recogniser: let the last MFMA retire before acc is read again)
@@ -1134,8 +1147,35 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             }
         }
         GANQ_TRACE(1, s, 2);
-        __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
+        // (the chain waves exchange data through LDS only and store nothing to memory: their barriers wait for LDS, not for
+        // the primed loads in flight)
+        if constexpr (PRIME) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
         GANQ_TRACE(1, s, 3);
+        // (after the barrier: the head may include the panel the P waves have just finished)
+        primed = false;
+        if constexpr (PRIME) {
+            // head of the next step's first segment (panel bG - 1, A blocks in LDS): batches 0 .. RING - 2
+            const int bGn = bG - 1, pldsn = max(bGn + 2, pbase);
+            const int nbatn = nb - 1 - pldsn + 1;
+            if (bGn >= 0 && nbatn > 0) {
+                const int ctn = SKR * bGn + gw;
+#pragma unroll
+                for (int u = 0; u < RING - 1; ++u) {
+                    const bool real = u < nbatn;
+                    const int ps = nb - 1 - min(u, nbatn - 1);
+                    const uint32_t sB = (uint32_t)lr_block(ctn, ps, NT, nb) * (uint32_t)SBLKB;
+                    const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
+                    const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * SBLK + lane * 4);
+#pragma unroll
+                    for (int j = 0; j < SKR; ++j) {
+                        rb[u][j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * j, (int)sB, 0));
+                        ra[u][j] = Al[j * 64];
+                    }
+                }
+                primed = true;
+            }
+        }
         if (bG >= 0) {
             // ---- (G) part 2: the 64 columns of panel bG+1, descending; then publish R ------------------------
             if (bG + 1 <= nb - 1) {
@@ -1156,7 +1196,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             for (int r = 0; r < 4; ++r) Rp[bG & 1][rsub * 4 + r][16 * gw + c16] = acc[r];
         }
         GANQ_TRACE(1, s, 4);
-        __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
+        if constexpr (PRIME) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
         GANQ_TRACE(1, s, 5);
     }
 }
