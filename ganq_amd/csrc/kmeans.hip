@@ -280,6 +280,68 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
     km_lds_barrier();
 }
 
+// Radix-4 level of the resident kernel (the TOP of a DP layer): the positions S4 - 1 + t S4 are solved (S4 = 4 S), this level
+// solves the three positions in between, i = S - 1 + t S with t % 4 != 3, each bounded by the argmins of the nearest solved
+// positions on its left and right.  Half as many levels as the binary scheme for 1.5 times the candidates -- up here a level
+// costs its latency (barriers, reductions), not its work.  G lanes per node (a power of two): up to 64 reduce by shuffles,
+// more go through the per-wave partials in LDS.  Same (cost, leftmost j) order as everywhere.
+// Radix-4 steps run while the new spacing is at least KM_R4_MIN (0x7fffffff: binary levels only).  Measured, 4096x4096: binary
+// only 15.5 ms, down to spacing 64: 15.0, 16: 15.3, 4: 18.6 (further down a level is bound by its work, which grows by half);
+// 1024x2048 with two workgroups per CU: 1.96 / 1.78 / 1.75 / 1.69 ms.
+#ifndef KM_R4_MIN
+#define KM_R4_MIN (MINW == 8 ? 4 : 64)
+#endif
+__device__ __forceinline__ void km_level_r4(const double* cw, const double* cwx, const double* cwxx, const double* dprev, uint16_t* acur,
+                                            double* dcur, int* ag, int S, int n, double* red_c, int* red_j) {
+    const int tid = threadIdx.x;
+    const int T = (n - 1) / S;        // positions i = S - 1 + t S < n - 1
+    const int cntU = T - T / 4;       // ... that are not solved yet
+    if (cntU <= 0) return;            // uniform
+    int G = 1;
+    while (G < KL_THREADS && G * 2 * cntU <= KL_THREADS) G <<= 1;
+    const int lg = tid & (G - 1);
+    const int per_pass = KL_THREADS / G;
+    for (int u0 = 0; u0 < cntU; u0 += per_pass) {  // one pass unless there are more nodes than threads (never at the top)
+        const int u = u0 + tid / G;
+        const bool valid = u < cntU;
+        const int t = (u / 3) * 4 + u % 3;
+        const int i = S - 1 + t * S;
+        double bc = INFINITY;
+        int bj = 0x7fffffff;
+        if (valid) {
+            const int left = i - ((t & 3) + 1) * S;
+            const int right = min(i + (3 - (t & 3)) * S, n - 1);
+            const int lo = left >= 0 ? (int)acur[left] : 0;
+            const int hi = max(lo, min(i, (int)acur[right]));
+            const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
+            for (int j = lo + lg; j <= hi; j += G)
+                km_better_asc(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+        }
+        for (int off = min(G, 64) >> 1; off > 0; off >>= 1) {
+            const double oc = __shfl_xor(bc, off);
+            const int oj = __shfl_xor(bj, off);
+            km_better(bc, bj, oc, oj);
+        }
+        if (G > 64) {
+            if ((tid & 63) == 0) {
+                red_c[tid >> 6] = bc;
+                red_j[tid >> 6] = bj;
+            }
+            km_lds_barrier();
+            if (lg == 0 && valid) {
+                const int w0 = tid >> 6;
+                for (int w = 1; w < G / 64; ++w) km_better(bc, bj, red_c[w0 + w], red_j[w0 + w]);
+            }
+        }
+        if (lg == 0 && valid) {
+            dcur[i] = bc;
+            ag[i] = bj;
+            acur[i] = (uint16_t)bj;
+        }
+        km_lds_barrier();
+    }
+}
+
 // MINW = waves per SIMD the register allocation must allow: 4 (one workgroup per CU) or 8 (two, when two rows' arrays
 // fit the LDS together: n <= 2.3 k)
 template <int MINW>
@@ -335,7 +397,15 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                         }
                     }
                 }
-                __syncthreads();
+                // a pass with j < 64 pairs elements of the same wave (thread t holds t, t + 1024, ..): it only has to wait for
+                // that wave's own LDS traffic; the workgroup meets before the next pass that reaches across waves
+                // (a pass that reached across waves itself must also be complete for everybody before anyone goes on)
+                const int jn = j > 1 ? (j >> 1) : k;  // distance of the next pass
+                if (j >= 64 || jn >= 64 || (j == 1 && k == P)) __syncthreads();
+                else {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         for (int u = tid; u < n; u += KL_THREADS) {
@@ -435,7 +505,13 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
             }
             KM_STAMP(3);
             if (k == V - 1) break;  // only D[V-1][n-1] is needed from the last layer
-            for (int hs = P >> 1; hs >= 1; hs >>= 1) {
+            int sp = P;  // spacing of the solved positions (sp - 1 + t sp, and n - 1)
+            while ((sp >> 2) >= KM_R4_MIN) {  // radix-4 steps at the top
+                sp >>= 2;
+                km_level_r4(cw, cwx, cwxx, dprev, acur, dcur, ag, sp, n, red_c, red_j);
+                KM_STAMP(4 + (31 - __builtin_clz(sp)));
+            }
+            for (int hs = sp >> 1; hs >= 1; hs >>= 1) {
                 const int cnt = (n - 1 > hs - 1) ? ((n - 1 - (hs - 1) + 2 * hs - 1) / (2 * hs)) : 0;
                 if (cnt == 0) continue;
                 int G = 1;
@@ -566,7 +642,15 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
                         }
                     }
                 }
-                __syncthreads();
+                // a pass with j < 64 pairs elements of the same wave (thread t holds t, t + 1024, ..): it only has to wait for
+                // that wave's own LDS traffic; the workgroup meets before the next pass that reaches across waves
+                // (a pass that reached across waves itself must also be complete for everybody before anyone goes on)
+                const int jn = j > 1 ? (j >> 1) : k;  // distance of the next pass
+                if (j >= 64 || jn >= 64 || (j == 1 && k == P)) __syncthreads();
+                else {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         for (int u = tid; u < n; u += KL_THREADS) {

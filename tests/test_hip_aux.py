@@ -90,7 +90,10 @@ def test_cholesky_not_positive_definite_raises(hip):
 
 # ------------------------------------------------------------------------------------------ k-means
 @pytest.mark.parametrize("m,n,V,seed", [(8, 64, 4, 1), (32, 300, 16, 2), (16, 1024, 8, 3), (5, 4096, 16, 4), (3, 17, 16, 5),
-                                        (700, 256, 16, 6), (2, 4700, 16, 7), (2, 4800, 16, 8), (3, 1, 4, 9), (2, 2, 4, 10)])
+                                        (700, 256, 16, 6), (2, 4700, 16, 7), (2, 4800, 16, 8), (3, 1, 4, 9), (2, 2, 4, 10),
+                                        # every CU busy (one / two workgroups per CU): the ordering bugs of a workgroup-wide sort or
+                                        # level scheme are timing-dependent and do not show on a handful of rows
+                                        (384, 4096, 16, 11), (640, 2048, 16, 12)])
 def test_kmeans_vs_oracle(hip, oracle, m, n, V, seed):
     rng = np.random.default_rng(seed)
     W = (0.02 * rng.standard_normal((m, n))).astype(np.float16).astype(np.float32)
