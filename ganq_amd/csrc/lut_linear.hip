@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NW * 64) void lut_mfma_kernel(const uint16_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Decode kernel (M <= 32), one memory round trip.  At decode sizes the packed weight of a layer (8 MB at 4096 x 4096 x
+// Decode kernel (M <= 32, out_features >= 128), one memory round trip.  At decode sizes the packed weight of a layer (8 MB at 4096 x 4096 x
 // 4 bit) is smaller than the chip's bandwidth-latency product (8 TB/s x ~2 us = 16 MB): the kernel is bound by how many
 // loads it keeps in flight, not by bandwidth.  So: one workgroup of 16 waves per 16 (NT = 1) or 32 (NT = 2) output
 // features -- 256 workgroups at m = 4096, one per CU --, the waves split in_features among themselves, and every wave
@@ -630,7 +630,9 @@ static LutPlan lut_plan(int64_t M, int64_t m, int64_t n, int bits) {
     const int nkb = (int)(n >> 5);
     const int inwg_env = (int)opt_get(OPT_LUT_INWG);
     // enough workgroups to occupy the chip, and a reduction buffer that fits LDS (two row tiles)
-    p.inwg = inwg_env >= 0 ? (inwg_env != 0 && M <= 32) : (M <= 32 && m >= 1024);
+    // (from 128 output features: 512 x 2048 takes 3.9 us with the decode kernel against 7.1 with the split-K kernel, 768 x 768
+    // 3.6 against 6.3 -- the latter slower than fp16 F.linear)
+    p.inwg = inwg_env >= 0 ? (inwg_env != 0 && M <= 32) : (M <= 32 && m >= 128);
     p.nt = 1;
     if (p.inwg) {
         const int nt_opt = (int)opt_get(OPT_LUT_NT);

@@ -153,7 +153,7 @@ def test_pack_roundtrip_and_layout(hip, bits):
                                               (4, 16, torch.bfloat16, 200, 512), (3, 17, torch.float16, 77, 2080),
                                               (4, 33, torch.bfloat16, 45, 4128), (2, 64, torch.float16, 130, 1056),
                                               (3, 1, torch.float16, 1, 32), (4, 64, torch.float16, 4096, 11008),
-                                              # decode kernel (out_features >= 1024): one and two row tiles, 16 and 32 features
+                                              # decode kernel (out_features >= 128; the cases above with 200 / 130 features too): one and two row tiles, 16 and 32 features
                                               # per workgroup (from 8192), ragged and odd out_features, every bit width
                                               (4, 1, torch.float16, 1024, 512), (4, 20, torch.float16, 1024, 512),
                                               (3, 32, torch.bfloat16, 2048, 1024), (2, 24, torch.float16, 1500, 256),

@@ -46,7 +46,7 @@ def test_outlier_split_matches_algorithm_2(hip, m, n, ratio):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,m,n,ratio", [(1, 256, 1024, 0.01), (7, 100, 512, 0.1), (64, 4096, 4096, 0.005), (3, 48, 2048, 0.0),
-                                         # decode kernel (M <= 32, out_features >= 1024): the sparse entries are added inside the
+                                         # decode kernel (M <= 32, out_features >= 128): the sparse entries are added inside the
                                          # LUT kernel's launch; 16 / 32 features per workgroup, one / two row tiles
                                          (1, 4096, 1024, 0.01), (16, 2048, 512, 0.05), (20, 1024, 768, 0.02), (3, 8192, 256, 0.03),
                                          (1, 1500, 512, 0.0),
