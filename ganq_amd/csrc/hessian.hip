@@ -88,9 +88,10 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
             uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
             if constexpr (FAST) {
                 const int tc = min(t, rows - 1);
+                // (rows past the end are zeroed where the slab is filed, in sstore: a select HERE makes the compiler wait for the
+                // load it has just issued -- vmcnt(0) right behind every pair of loads, the whole round trip exposed per slab)
                 va = *reinterpret_cast<const uint4*>(X + (int64_t)tc * n + u0 + f8);
                 vb = *reinterpret_cast<const uint4*>(X + (int64_t)tc * n + v0 + f8);
-                if (t >= rows) va = vb = make_uint4(0, 0, 0, 0);
             } else {
               if (t < rows) {
                 const uint16_t* pa = X + (int64_t)t * n + u0 + f8;
@@ -106,13 +107,18 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
             rb[h] = vb;
         }
     };
-    auto sstore = [&](int buf, const uint4 (&ra)[HL], const uint4 (&rb)[HL]) {
+    // t0 = first token of the slab: a slab that reaches past `rows` (uniform per workgroup: only the last ones do) has
+    // its surplus token rows zeroed here
+    auto sstore = [&](int buf, int t0, const uint4 (&ra)[HL], const uint4 (&rb)[HL]) {
+        const bool tail = t0 + HK > rows;
 #pragma unroll
         for (int h = 0; h < HL; ++h) {
             const int idx = h * 256 + tid;
             const int t = idx >> 4, f8 = (idx & 15) * 8;
-            *reinterpret_cast<uint4*>(&Xa[buf][t][f8]) = ra[h];
-            *reinterpret_cast<uint4*>(&Xb[buf][t][f8]) = rb[h];
+            uint4 va = ra[h], vb = rb[h];
+            if (tail && t0 + t >= rows) va = vb = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&Xa[buf][t][f8]) = va;
+            *reinterpret_cast<uint4*>(&Xb[buf][t][f8]) = vb;
         }
     };
 
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
         gload(fast_tag, 0, ra4[0], rb4[0]);
         gload(fast_tag, HK, ra4[1], rb4[1]);
         gload(fast_tag, 2 * HK, ra4[2], rb4[2]);
-        sstore(0, ra4[0], rb4[0]);
+        sstore(0, 0, ra4[0], rb4[0]);
         __syncthreads();
         // whole rounds of four slabs; slabs past the end are zeros (they add nothing)
         for (int s = 0; s < nslab; s += 4) {
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
             for (int jj = 0; jj < 4; ++jj) {
                 gload(fast_tag, (s + jj + 3) * HK, ra4[(jj + 3) & 3], rb4[(jj + 3) & 3]);
                 compute((s + jj) & 1);
-                sstore((s + jj + 1) & 1, ra4[(jj + 1) & 3], rb4[(jj + 1) & 3]);
+                sstore((s + jj + 1) & 1, (s + jj + 1) * HK, ra4[(jj + 1) & 3], rb4[(jj + 1) & 3]);
                 __syncthreads();
             }
         }
