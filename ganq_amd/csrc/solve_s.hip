@@ -1247,8 +1247,23 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
     float* errt = static_cast<float*>(workspace);
     const float* Lr = reinterpret_cast<const float*>(static_cast<char*>(workspace) + lo.errt_bytes);
     const int tiles = (int)((m + SR - 1) / SR);
-    // the Err blocks of the top SOLVE_LDS_PANELS panels (the ones every later panel re-reads) stay in LDS
-    const int pbase = std::max(0, lo.nb - SOLVE_LDS_PANELS);
+    // the Err blocks of the top SOLVE_LDS_PANELS panels (the ones every later panel re-reads) stay in LDS -- as many of them
+    // as the 160 KB of a CU leave next to the kernel's static buffers (asked of the runtime once: the static size moves with
+    // the compiler and the build options, and the margin at SOLVE_LDS_PANELS is a few hundred bytes)
+    static const int lds_panels = [] {
+        hipFuncAttributes fa{};
+        int fit = SOLVE_LDS_PANELS;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(solve_s_kernel<true>)) == hipSuccess) {
+            hipFuncAttributes fb{};
+            size_t stat = fa.sharedSizeBytes;
+            if (hipFuncGetAttributes(&fb, reinterpret_cast<const void*>(solve_s_kernel<false>)) == hipSuccess)
+                stat = std::max(stat, fb.sharedSizeBytes);
+            const size_t room = stat < 160u * 1024u ? 160u * 1024u - stat : 0u;
+            fit = (int)std::min<size_t>((size_t)SOLVE_LDS_PANELS, room / SBLKB);
+        }
+        return fit;
+    }();
+    const int pbase = std::max(0, lo.nb - lds_panels);
     const size_t smem = (size_t)(lo.nb - pbase) * SBLKB;
     {
         int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(solve_s_kernel<true>), smem);
