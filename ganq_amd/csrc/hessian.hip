@@ -43,8 +43,16 @@ __device__ __forceinline__ f32x16 mfma16(s8v a, s8v b, f32x16 c) {
     }
 }
 
+#ifdef GANQ_HESS_TRACE
+__device__ unsigned long long g_hess_trace[8];  // developer: cycles of workgroup 0 / wave 0 in the phases of a slab step
+#define HESS_T(k) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        g_hess_trace[k] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define HESS_T(k) do {} while (0)
+#endif
+
 template <bool BF16>
-__global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows,
+__global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows,
                                                       int n, float decay, float scale, int tiles_per_side,
                                                       const uint32_t* __restrict__ tile_order) {
     __shared__ __align__(16) uint16_t Xs[2][2][HK][HP];  // [operand][buffer][token][feature]; reused by the epilogue
@@ -78,7 +86,19 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
     // the end is clamped and zeroed afterwards), so that the compiler can count the loads in flight instead of
     // draining them at every slab
     // (rows == 0, an empty batch, only decays H: the fast path's clamp to row rows-1 would read out of bounds)
-    const bool fast = rows > 0 && (u0 + HT <= n) && (v0 + HT <= n) && ((n & 7) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool fast = rows > 0 && (u0 + HT <= n) && (v0 + HT <= n) && ((n & 7) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+                      ((int64_t)(rows + 4 * HK) * n * 2 < (1ll << 31));  // 32-bit offsets of the buffer loads (incl. the look-ahead)
+    // byte offsets of this thread's chunks inside a slab (token row idx >> 4, feature chunk idx & 15); a slab spans at most
+    // HK * n * 2 bytes, far below 4 GB
+    uint32_t offA[HL], offB[HL];
+#pragma unroll
+    for (int h = 0; h < HL; ++h) {
+        const int idx = h * 256 + tid;
+        offA[h] = (uint32_t)(((idx >> 4) * n + u0 + (idx & 15) * 8) * 2);
+        offB[h] = (uint32_t)(((idx >> 4) * n + v0 + (idx & 15) * 8) * 2);
+    }
+    const __amdgpu_buffer_rsrc_t rsrcX =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X), 0, (int)((int64_t)rows * n * 2), 0x00020000);
     auto gload = [&](auto fast_tag, int t0, uint4 (&ra)[HL], uint4 (&rb)[HL]) {
         constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
@@ -87,11 +107,16 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
             const int t = t0 + (idx >> 4), f8 = (idx & 15) * 8;
             uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
             if constexpr (FAST) {
-                const int tc = min(t, rows - 1);
                 // (rows past the end are zeroed where the slab is filed, in sstore: a select HERE makes the compiler wait for the
                 // load it has just issued -- vmcnt(0) right behind every pair of loads, the whole round trip exposed per slab)
-                va = *reinterpret_cast<const uint4*>(X + (int64_t)tc * n + u0 + f8);
-                vb = *reinterpret_cast<const uint4*>(X + (int64_t)tc * n + v0 + f8);
+                // buffer loads: the slab's byte offset in an SGPR, this thread's constant offset inside a slab in a VGPR -- no
+                // per-load 64-bit address arithmetic (it was a fifth of a slab step: 610 of 2900 cycles by the stamps); the
+                // resource ends with the last token row, so rows past the end read as zeros by themselves
+                (void)t;
+                (void)f8;
+                const int soff = t0 * n * 2;
+                va = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offA[h], soff, 0));
+                vb = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offB[h], soff, 0));
             } else {
               if (t < rows) {
                 const uint16_t* pa = X + (int64_t)t * n + u0 + f8;
@@ -163,13 +188,20 @@ __global__ __launch_bounds__(256) void hessian_kernel(float* __restrict__ H, con
         sstore(0, 0, ra4[0], rb4[0]);
         __syncthreads();
         // whole rounds of four slabs; slabs past the end are zeros (they add nothing)
+#ifdef GANQ_HESS_TRACE
+        unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
         for (int s = 0; s < nslab; s += 4) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 gload(fast_tag, (s + jj + 3) * HK, ra4[(jj + 3) & 3], rb4[(jj + 3) & 3]);
+                HESS_T(0);
                 compute((s + jj) & 1);
+                HESS_T(1);
                 sstore((s + jj + 1) & 1, (s + jj + 1) * HK, ra4[(jj + 1) & 3], rb4[(jj + 1) & 3]);
+                HESS_T(2);
                 __syncthreads();
+                HESS_T(3);
             }
         }
     };
@@ -265,6 +297,15 @@ const uint32_t* tile_table(int tiles, hipStream_t stream) {
     return dev;
 }
 }  // namespace
+
+#ifdef GANQ_HESS_TRACE
+extern "C" int ganq_debug_hess_trace(unsigned long long* out8) {
+    GANQ_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ganq::g_hess_trace), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {};
+    GANQ_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ganq::g_hess_trace), z, sizeof(z)));
+    return 0;
+}
+#endif
 
 extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
                                   int64_t batch, void* stream_) {
