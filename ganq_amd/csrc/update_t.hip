@@ -37,13 +37,22 @@ namespace ganq {
 #ifndef ACC_TW
 #define ACC_TW 8
 #endif
+// ACC_VH = 32-column halves per chunk.  2: every expanded one-hot fragment (the kernel's vector work: 14 instructions per
+// fragment) serves 8 MFMAs instead of 4 -- two rows per wave instead of four keep the accumulators at 128 registers, and
+// 128-wide u tiles keep the two staged digit tiles of 64 columns inside the LDS.  Measured on MI355X, 4096x4096: 2.58 ms
+// against 2.22 ms for the default (half the rows per workgroup stream every digit tile twice as often): the fragment
+// expansion is not what bounds the kernel.
+#ifndef ACC_VH
+#define ACC_VH 1
+#endif
 #ifndef ACC_UT
-#define ACC_UT 256
+#define ACC_UT (ACC_VH == 2 ? 128 : 256)
 #endif
 constexpr int TW = ACC_TW;      // waves per workgroup
-constexpr int RW = 4;           // rows per wave
+constexpr int VH = ACC_VH;
+constexpr int RW = VH == 2 ? 2 : 4;  // rows per wave
 constexpr int TR = TW * RW;     // rows of W per workgroup
-constexpr int VCH = 32;         // v columns per chunk (two 16-wide MFMA column tiles)
+constexpr int VCH = 32 * VH;    // v columns per chunk (32 per MFMA column tile)
 constexpr int UT = ACC_UT;      // u per staged tile (UT / 64 MFMA steps of 64)
 constexpr int KS64 = UT / 64;
 constexpr int UC16 = UT / 16;   // 16-byte pieces per tile row
@@ -281,13 +290,15 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
         const int v0 = c * VCH;
         const int t_first = (v0 + 1) / UT;
         if (t_first >= ntile) continue;
-        v16i acc[RW / 2][NPL];
+        v16i acc[RW / 2][VH][NPL];
 #pragma unroll
         for (int p = 0; p < RW / 2; ++p)
 #pragma unroll
-            for (int d = 0; d < NPL; ++d)
+            for (int vh = 0; vh < VH; ++vh)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[p][d][r] = 0;
+                for (int d = 0; d < NPL; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][vh][d][r] = 0;
 
         st_t0 = __builtin_amdgcn_s_memtime();
         __syncthreads();  // previous chunk's last tile fully consumed
@@ -306,12 +317,14 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
             const int buf = (t - t_first) & 1;
             if (t + 1 < ntile) gload(v0, t + 1);
             const char* Bt = Bbuf + buf * BTILE + i32 * BROW + 16 * kb;
-            auto read_b = [&](int ks, int kh, v4i (&bf)[NPL]) {
+            auto read_b = [&](int ks, int kh, v4i (&bf)[VH][NPL]) {
 #pragma unroll
-                for (int d = 0; d < NPL; ++d)
-                    bf[d] = *reinterpret_cast<const v4i*>(Bt + d * (VCH * BROW) + ks * 64 + kh * 32);
+                for (int vh = 0; vh < VH; ++vh)
+#pragma unroll
+                    for (int d = 0; d < NPL; ++d)
+                        bf[vh][d] = *reinterpret_cast<const v4i*>(Bt + (d * VCH + 32 * vh) * BROW + ks * 64 + kh * 32);
             };
-            v4i bf[2][NPL];
+            v4i bf[2][VH][NPL];
             read_b(0, 0, bf[0]);
 #pragma unroll
             for (int ks = 0; ks < KS64; ++ks) {
@@ -328,8 +341,10 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 #pragma unroll
                         for (int d = 0; d < 4; ++d) af[d] = (int)((((b16 >> (4 * d)) & 0xfu) * 0x00204081u) & 0x01010101u);
 #pragma unroll
-                        for (int d = 0; d < NPL; ++d)
-                            acc[p][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[hh & 1][d], acc[p][d], 0, 0, 0);
+                        for (int vh = 0; vh < VH; ++vh)
+#pragma unroll
+                            for (int d = 0; d < NPL; ++d)
+                                acc[p][vh][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[hh & 1][vh][d], acc[p][vh][d], 0, 0, 0);
                     }
                 }
             }
@@ -339,8 +354,9 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
         { const long long tt = __builtin_amdgcn_s_memtime(); st_loop += tt - st_t0; st_t0 = tt; }
         // bucket the chunk's columns by their code: Mrow[row][a][b] += sum_d 256^d Y_d[(row, a)][v], b = Q[row][v]
         // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-        {
-            const int v = v0 + i32;
+#pragma unroll
+        for (int vh = 0; vh < VH; ++vh) {
+            const int v = v0 + 32 * vh + i32;
 #pragma unroll
             for (int p = 0; p < RW / 2; ++p) {
                 uint32_t bq[2];
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
                     const int h = i >> 4, a = i & 15;
                     long long val = 0;
 #pragma unroll
-                    for (int d = 0; d < NPL; ++d) val += (long long)acc[p][d][reg] << (8 * d);
+                    for (int d = 0; d < NPL; ++d) val += (long long)acc[p][vh][d][reg] << (8 * d);
                     const uint32_t b = bq[h];
                     if (b < 16u && val != 0)
                         atomicAdd(reinterpret_cast<unsigned long long*>(&Mrow[wv][2 * p + h][a * 16 + b]),
