@@ -323,13 +323,23 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
     const uint32_t* order = tile_table(tiles, stream);
     if (!order) return fail(-100, "ganq_hessian_accum: could not build the tile table");
     ProfScope prof(KID_HESSIAN, stream);
-    if (dtype == 1) {
-        hipLaunchKernelGGL(hessian_kernel<true>, dim3(blocks), dim3(256), 0, stream, H, static_cast<const uint16_t*>(X),
-                           (int)rows, (int)n, decay, scale, tiles, order);
-    } else {
-        hipLaunchKernelGGL(hessian_kernel<false>, dim3(blocks), dim3(256), 0, stream, H, static_cast<const uint16_t*>(X),
-                           (int)rows, (int)n, decay, scale, tiles, order);
-    }
-    GANQ_LAUNCH_CHECK();
+    // The kernel's fast path addresses X through 32-bit buffer offsets: a batch of more than ~2 GB goes in pieces of whole
+    // slabs -- the first with the batch's decay, the others adding to it (decay 1) with the same scale; the same sum in the
+    // same token order.
+    const int64_t piece_max = std::max<int64_t>(HK, (((int64_t)1 << 31) / (2 * n) - 4 * HK - 1) / HK * HK);
+    const uint16_t* Xp = static_cast<const uint16_t*>(X);
+    int64_t done = 0;
+    do {
+        const int64_t piece = std::min(rows - done, piece_max);
+        const float dec = done == 0 ? decay : 1.0f;
+        if (dtype == 1)
+            hipLaunchKernelGGL(hessian_kernel<true>, dim3(blocks), dim3(256), 0, stream, H, Xp + done * n, (int)piece, (int)n, dec, scale,
+                               tiles, order);
+        else
+            hipLaunchKernelGGL(hessian_kernel<false>, dim3(blocks), dim3(256), 0, stream, H, Xp + done * n, (int)piece, (int)n, dec, scale,
+                               tiles, order);
+        GANQ_LAUNCH_CHECK();
+        done += piece;
+    } while (done < rows);
     return 0;
 }

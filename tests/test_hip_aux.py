@@ -47,6 +47,33 @@ def test_hessian_golden(hip, name):
     assert rel_fro(Hn, g["H_raw"]) < 1e-6
 
 
+def test_hessian_batch_beyond_the_offset_window_is_split(hip):
+    # the kernel's fast path reaches X through 32-bit buffer offsets; a batch of more than 2 GB is accumulated in pieces
+    # (first piece with the batch's decay, the others adding to it): same result as the batch in two separate halves
+    n, rows = 2048, 540_000  # 2.2 GB of fp16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = (0.5 * torch.randn(rows, n, device="cuda", generator=g)).half()
+    H0 = torch.randn(n, n, device="cuda", generator=g)
+    H0 = (H0 + H0.T).contiguous()
+    H = H0.clone()
+    hip.hessian_accum(H, X, 3, 5)  # H <- H * 3/8 + (2/8) X^T X
+    ref = H0.double() * (3.0 / 8.0)
+    for a in range(0, rows, 60_000):  # fp64 reference in slices (the fp64 copy of all of X would be 8.8 GB)
+        xs = X[a:a + 60_000].double()
+        ref += (2.0 / 8.0) * (xs.T @ xs)
+    err = float((H.double() - ref).norm() / ref.norm())
+    assert err < 3e-5, err  # fp32 accumulators over 540 000 tokens (6e-6 measured); a lost or doubled piece would be 0.4
+    assert torch.equal(H, H.T)
+    # the same batch handed over in two calls (each inside the window): fp32 sums in the same token order
+    H2 = H0.clone()
+    half = rows // 2 // 32 * 32
+    hip.hessian_accum(H2, X[:half], 3, 5)                 # H * 3/8 + (2/8) X1^T X1
+    H3 = torch.zeros_like(H2)
+    hip.hessian_accum(H3, X[half:], 0, 8)                 # (2/8) X2^T X2
+    err2 = float((H.double() - (H2.double() + H3.double())).norm() / ref.norm())
+    assert err2 < 2e-5, err2  # different grouping of the fp32 sums: 4e-6 measured
+
+
 @pytest.mark.parametrize("rows,n,dtype", [(100, 72, torch.float16), (333, 264, torch.bfloat16), (2048, 512, torch.float16)])
 def test_hessian_vs_oracle_shapes(hip, oracle, rows, n, dtype):
     g = torch.Generator().manual_seed(rows + n)
