@@ -36,7 +36,7 @@ def find_modules(layer: nn.Module, names: Sequence[str]) -> Dict[str, nn.Module]
 class ModuleLooper:
     def __init__(self, processor, layers: Sequence[nn.Module], layer_modules: List[List[str]],
                  layers_prefix: str = "model.layers", share_group_hessian: bool = False, early_exit: bool = True,
-                 cache_outputs: bool = True, cache_budget_bytes: int = 48 << 30):
+                 cache_outputs: bool = True, cache_budget_bytes: int = 48 << 30, concurrent_group: bool = True):
         # share_group_hessian: the modules of one group ([q,k,v], [gate,up]) receive the same inputs, so the first
         # one accumulates the Hessian and runs the prologue (permutation, factor, damping) for all of them; the
         # reference does both once per module.  Same numbers, less work.  Only valid when the groups really share
@@ -54,10 +54,63 @@ class ModuleLooper:
         # the layer is done (up to cache_budget_bytes).  Turn it off together with early_exit for unusual layers.
         self.cache_outputs = cache_outputs
         self.cache_budget_bytes = int(cache_budget_bytes)
+        # concurrent_group (with share_group_hessian, on a GPU): once the group's leader has finished the shared prologue,
+        # its followers are quantized on side streams beside the leader's own loop.  The solve of a small module is a
+        # latency chain that leaves most of the chip idle (k / v projections: 32 workgroups on 256 CUs), and the modules
+        # of a group are independent given the prologue.  Same numbers: every module's work is the same sequence of
+        # launches on its own stream.
+        self.concurrent_group = concurrent_group
         self.processor = processor
         self.layers = layers
         self.layer_modules = layer_modules
         self.layers_prefix = layers_prefix
+
+    def _process_group(self, todo, named):
+        """processor.process() for the modules of one group: one after the other, or -- followers of a shared prologue on a
+        GPU -- the followers on side streams in worker threads, started by the leader the moment its prologue is shared."""
+        tasks = self.processor.tasks
+        followers = [n for n in todo if getattr(tasks[n], "_group_leader", None) is not None]
+        leaders = [n for n in todo if n not in followers]
+        dev = next(iter(named.values())).module.weight.device if named else None
+        if not (self.concurrent_group and followers and len(leaders) == 1 and dev is not None and dev.type == "cuda"
+                and all(tasks[f]._group_leader is tasks[leaders[0]] for f in followers)):
+            for n in todo:
+                self.processor.process(named[n])
+            return
+        import threading
+
+        main = torch.cuda.current_stream(dev)
+        errors, threads, streams = [], [], []
+
+        def run(n, stream):
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(stream):
+                    self.processor.process(named[n])
+            except BaseException as e:  # re-raised on the caller's thread
+                errors.append(e)
+
+        def start_followers():
+            for n in followers:
+                st = torch.cuda.Stream(device=dev)
+                st.wait_stream(main)  # the shared prologue was enqueued on the leader's stream
+                th = threading.Thread(target=run, args=(n, st), name=f"ganq-{n}")
+                streams.append(st)
+                threads.append(th)
+                th.start()
+
+        tasks[leaders[0]]._on_prologue_shared = start_followers
+        try:
+            self.processor.process(named[leaders[0]])
+        finally:
+            for th in threads:
+                th.join()
+            for st in streams:
+                main.wait_stream(st)
+        if followers and not threads:  # the leader never reached the hand-over (it keeps its hook only while it lives)
+            for n in followers:
+                self.processor.process(named[n])
+        if errors:
+            raise errors[0]
 
     @torch.no_grad()
     def loop(self, layer_inputs: List[torch.Tensor], layer_kwargs: Optional[List[dict]] = None,
@@ -143,6 +196,7 @@ class ModuleLooper:
                         pass
                 for h in handles:
                     h.remove()
+                todo = []
                 for n in mine:
                     if self.processor.is_skipped(named[n]):
                         continue
@@ -157,7 +211,9 @@ class ModuleLooper:
                                       f"(a MoE expert may lack calibration tokens routed to it)")
                         self.processor.skip(named[n])
                         continue
-                    self.processor.process(named[n])
+                    todo.append(n)
+                self._process_group(todo, named)
+                for n in todo:
                     if self.cache_outputs:
                         cache_module(mods[n])
                     if progress:

@@ -300,6 +300,10 @@ class GPTQ:
                           "nsamples": self.nsamples}
                 for f in followers:
                     f._leader_prologue = shared
+                # the followers can start from here (ModuleLooper runs them on side streams beside this module's own loop)
+                hook = getattr(self, "_on_prologue_shared", None)
+                if hook is not None:
+                    hook()
 
         Q, Losses, scale, zero = self._perform_quantization_loop(W, Hinv, blocksize, perm, invperm)
 

@@ -268,6 +268,33 @@ def test_looper_shared_group_hessian_is_identical():
 
 
 @torch.no_grad()
+def test_looper_concurrent_followers_are_identical():
+    # the followers of a group's shared prologue run on side streams beside the leader's loop: every module's result and the
+    # layer's outputs must be bit-identical to the one-after-the-other run, also with a wider layer (several batches, 2 layers)
+    from ganq_amd.looper.gptq_processor import GPTQProcessor
+    from ganq_amd.looper.module_looper import ModuleLooper
+    from ganq_amd.quantization import QuantizeConfig
+
+    res, outs = [], []
+    for conc in (False, True):
+        torch.manual_seed(0)
+        model = nn.Module()
+        model.layers = nn.ModuleList([ToyLayer(256, 512), ToyLayer(256, 512)])
+        model = model.half().cuda()
+        xs = [torch.randn(2, 64, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3 + i)).half()
+              for i in range(3)]
+        proc = GPTQProcessor(QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=3))
+        out = ModuleLooper(proc, model.layers, [["q_proj", "k_proj", "v_proj"], ["out_proj"], ["fc1"], ["fc2"]],
+                           layers_prefix="layers", share_group_hessian=True, concurrent_group=conc).loop(xs)
+        res.append({k: (v["ganq_q"].clone(), v["ganq_lut"].clone()) for k, v in proc.results().items()})
+        outs.append([o.clone() for o in out])
+    assert len(res[0]) == 12 and res[0].keys() == res[1].keys()
+    for k in res[0]:
+        assert torch.equal(res[0][k][0], res[1][k][0]) and torch.equal(res[0][k][1], res[1][k][1]), k
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+@torch.no_grad()
 def test_looper_early_exit_is_identical():
     # stopping a group's calibration forward once its modules have seen the batch must not change any statistic
     from ganq_amd.looper.gptq_processor import GPTQProcessor
