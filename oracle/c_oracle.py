@@ -195,3 +195,16 @@ def lut_linear(x_half, Q, lut_half, bias_half=None):
                                  None if bias is None else _p(bias.view(np.uint16), _u16p), _i64(M), _i64(m),
                                  _i64(n), V, _p(y, _f32p))
     return y
+
+
+def det_cholesky(A):
+    """reproducible lower Cholesky factor of a symmetric fp32 matrix (input generator of the large golden cases; see the
+    C function's comment) -> fp32 [n,n]"""
+    A = _f32(A)
+    n = A.shape[0]
+    assert A.shape == (n, n)
+    out = np.empty((n, n), dtype=np.float32)
+    rc = lib().ganq_oracle_det_cholesky(_p(A, _f32p), _i64(n), _p(out, _f32p))
+    if rc:
+        raise RuntimeError(f"ganq_oracle_det_cholesky: pivot {rc - 1} is not positive" if rc > 0 else "out of memory")
+    return out

@@ -645,3 +645,38 @@ int ganq_oracle_lut_linear(const uint16_t* x, const uint8_t* Q, const uint16_t* 
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Reproducible Cholesky factor -- NOT a restatement of anything in the reference: an input generator for the
+ * large golden cases (tests/golden/exact_inputs.py).  Those cases hand the reference's own loop
+ * (ganq.py:456-646) a lower-triangular L that every box must be able to rebuild bit for bit from a seed; a
+ * LAPACK factorisation does not qualify (blocking, threads and instruction set change its rounding).  Here every
+ * entry is ONE ascending fp64 sum with separately rounded products (Cholesky-Crout),
+ *     L[i][j] = (A[i][j] - sum_{k<j} L[i][k] L[j][k]) / L[j][j],   L[j][j] = sqrt(A[j][j] - sum_{k<j} L[j][k]^2),
+ * so the result depends on nothing but A (threads split the rows of a column).  A [n,n] fp32 symmetric (lower
+ * triangle read), out [n,n] fp32 lower-triangular (upper part zero).  Returns j+1 when pivot j is not positive.
+ * ------------------------------------------------------------------------------------------ */
+int ganq_oracle_det_cholesky(const float* A, int64_t n, float* out) {
+    double* Ld = (double*)calloc((size_t)n * (size_t)n, sizeof(double));
+    if (!Ld) return -1;
+    int bad = 0;
+    for (int64_t j = 0; j < n && !bad; ++j) {
+        const double* Lj = Ld + j * n;
+        double s = (double)A[j * n + j];
+        for (int64_t k = 0; k < j; ++k) s -= Lj[k] * Lj[k];
+        if (!(s > 0.0)) { bad = (int)(j + 1); break; }
+        const double d = sqrt(s);
+        Ld[j * n + j] = d;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = j + 1; i < n; ++i) {
+            const double* Li = Ld + i * n;
+            double t = (double)A[i * n + j];
+            for (int64_t k = 0; k < j; ++k) t -= Li[k] * Lj[k];
+            Ld[i * n + j] = t / d;
+        }
+    }
+    if (!bad)
+        for (int64_t i = 0; i < n * n; ++i) out[i] = (float)Ld[i];
+    free(Ld);
+    return bad;
+}

@@ -1,0 +1,125 @@
+"""Large golden cases: the reference's OWN loop (`GANQ._perform_quantization_loop`, ganq.py:456-646) at n = 2048 and on a
+4096 x 4096 layer.  Build container only (`/root/reference` must exist):
+
+    python tests/golden/make_golden_large.py [case ...]
+
+The inputs of the loop (W, Xxt_damped, L, diag(Hinv), T0) come from tests/golden/exact_inputs.py -- every box rebuilds them
+bit for bit from the seed, so the fixture stores only their sha256 (an n x n fp32 L cannot be committed at these sizes) and
+what the reference produced:
+
+  Q_k      indices of every iteration (captured at torch.argmin, as make_golden.py does): stored as first iteration + XOR
+           deltas; the 4096 x 4096 case is hash-only -- sha256 of each Q_k plus one 64-bit digest per row
+  T_k      codebooks T_0 .. T_K (captured at torch.linalg.lstsq)
+  dists    quad_loss_2 of every iteration
+  Wq/Losses  sha256 / sums of the loop's outputs
+The reference object is constructed exactly as in make_golden.py; `self.L` / `self.Xxt_damped` (what gptq.py:288-300 leaves
+behind) are set from the generated inputs and the override point is called directly, so the prologue's LAPACK calls --
+which no other box could reproduce bit for bit -- stay out of the picture.  Stages pinned: a4/a5 S-solve, a6 T-update,
+a7 loss / best-of-K / outputs.
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import exact_inputs  # noqa: E402
+import ref_loader  # noqa: E402
+
+OUT = os.path.join(HERE, "large")
+
+CASES = [
+    dict(name="l128x2048_b4_k3", m=128, n=2048, bits=4, K=3, seed=201, tokens=4096, hash_only=False),
+    dict(name="l128x2048_b3_k3", m=128, n=2048, bits=3, K=3, seed=201, tokens=4096, hash_only=False),
+    dict(name="l128x2048_b4_k10", m=128, n=2048, bits=4, K=10, seed=202, tokens=4096, hash_only=False),
+    dict(name="l256x512_b2_k3", m=256, n=512, bits=2, K=3, seed=204, tokens=2048, hash_only=False),
+    dict(name="h4096x4096_b4_k2", m=4096, n=4096, bits=4, K=2, seed=203, tokens=8192, hash_only=True),
+]
+
+
+def run_case(c, ganq_mod, cfg_mod, NamedModule):
+    m, n, K, V = c["m"], c["n"], c["K"], 2 ** c["bits"]
+    t0 = time.time()
+    inp = exact_inputs.make(m, n, c["bits"], c["seed"], c["tokens"])
+    print(f"{c['name']}: inputs in {time.time() - t0:.1f} s", flush=True)
+    lin = torch.nn.Linear(n, m, bias=False).half()
+    qcfg = cfg_mod.QuantizeConfig(bits=c["bits"], quant_method="ganq", format="fake", act_sort="asc", l_damp_style="ganq",
+                                  dead="mean", desc_act=True, ganq_iterations=K, group_size=128, damp_percent=0.01)
+    g = ganq_mod.GANQ(NamedModule(lin, "fc1", "model.layers.0.fc1", 0), qcfg)
+    g.quantizer.configure(perchannel=True)
+    g.L = torch.from_numpy(inp["L"])
+    g.Xxt_damped = torch.from_numpy(inp["H"])
+    Hinv = torch.diag(torch.from_numpy(inp["hinv_diag"]))
+    T0 = torch.from_numpy(inp["T0"])
+
+    Qs = np.zeros((K, m, n), dtype=np.uint8)
+    rec = dict(step=0, lstsq=[], loss=[])
+    real_argmin, real_lstsq, real_loss = torch.argmin, torch.linalg.lstsq, ganq_mod.quad_loss_2
+    real_init = ganq_mod.GANQ._initialize_codebook_kmeans
+
+    def argmin_wrap(*a, **k):
+        out = real_argmin(*a, **k)
+        s = rec["step"]
+        Qs[s // n, :, n - 1 - s % n] = out.numpy().astype(np.uint8)
+        rec["step"] = s + 1
+        return out
+
+    def lstsq_wrap(A, B, *a, **k):
+        out = real_lstsq(A, B, *a, **k)
+        rec["lstsq"].append(out.solution.clone())
+        return out
+
+    def loss_wrap(Wm, Wq, G):
+        out = real_loss(Wm, Wq, G)
+        rec["loss"].append(float(out))
+        print(f"  iteration {len(rec['loss'])}: dist {float(out):.8g}  ({time.time() - t0:.0f} s)", flush=True)
+        return out
+
+    ganq_mod.GANQ._initialize_codebook_kmeans = lambda self, *a, **k: T0.clone()
+    torch.argmin, torch.linalg.lstsq, ganq_mod.quad_loss_2 = argmin_wrap, lstsq_wrap, loss_wrap
+    try:
+        Wq, Losses, _, _ = g._perform_quantization_loop(torch.from_numpy(inp["W"]).clone(), Hinv, 128)
+    finally:
+        ganq_mod.GANQ._initialize_codebook_kmeans = real_init
+        torch.argmin, torch.linalg.lstsq, ganq_mod.quad_loss_2 = real_argmin, real_lstsq, real_loss
+    assert rec["step"] == K * n and len(rec["lstsq"]) == K and len(rec["loss"]) == K
+    Ts = np.stack([inp["T0"]] + [s.mT.squeeze(-2).numpy() for s in rec["lstsq"]]).astype(np.float32)
+    dists = np.array(rec["loss"], dtype=np.float64)
+    best_k = int(np.argmin(dists))
+    # the loop's output is T_best.gather(Q_last) (the aliasing quirk, ganq.py:487,550,625-626)
+    assert np.array_equal(np.take_along_axis(Ts[best_k + 1], Qs[K - 1].astype(np.int64), axis=1), Wq.numpy())
+    out = dict(m=m, n=n, bits=c["bits"], K=K, seed=c["seed"], tokens=c["tokens"], hash_only=c["hash_only"],
+               T=Ts, dists=dists, T0=inp["T0"],
+               sha_Wq=exact_inputs.sha(Wq.numpy()), sha_Losses=exact_inputs.sha(Losses.numpy()),
+               losses_sum=np.float64(Losses.double().sum().item()),
+               sha_Q=np.array([exact_inputs.sha(Qs[k]) for k in range(K)]))
+    out.update({"sha_" + k: v for k, v in exact_inputs.hashes(inp).items()})
+    if c["hash_only"]:
+        out["Q_row_digest"] = np.stack([exact_inputs.row_digest(Qs[k]) for k in range(K)])
+    else:
+        out.update(exact_inputs.pack_q_trace(Qs))
+    return out
+
+
+def main():
+    ganq_mod, _gptq_mod, cfg_mod, NamedModule = ref_loader.load_reference(None)
+    torch.set_num_threads(os.cpu_count() or 1)
+    os.makedirs(OUT, exist_ok=True)
+    want = set(sys.argv[1:])
+    for c in CASES:
+        if want and c["name"] not in want:
+            continue
+        out = run_case(c, ganq_mod, cfg_mod, NamedModule)
+        path = os.path.join(OUT, c["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{c['name']}: dists={out['dists']} -> {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""The reference's own loop at n = 2048 and on a 4096 x 4096 layer (tests/golden/large/*.npz, make_golden_large.py):
+CPU oracle here (`-m "not gpu"`), the HIP path below (`-m gpu`).  Inputs are rebuilt bit for bit from the seed
+(tests/golden/exact_inputs.py; the fixture holds their sha256).  Bars: indices bit-exact against the REFERENCE's captured
+`torch.argmin` results, stage-wise on every iteration and free-running over all K; codebooks 1e-5, distances 1e-6."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, rel_fro
+
+sys.path.insert(0, GOLDEN_DIR)
+import exact_inputs  # noqa: E402
+
+LARGE = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "large", "*.npz")))
+TOL_T, TOL_LOSS = 1e-5, 1e-6
+_cache = {}
+
+
+def case(name):
+    if name not in _cache:
+        _cache.clear()  # one case in memory at a time (the 4096 x 4096 inputs are 200 MB)
+        fx = np.load(os.path.join(GOLDEN_DIR, "large", name + ".npz"))
+        inp = exact_inputs.make(int(fx["m"]), int(fx["n"]), int(fx["bits"]), int(fx["seed"]), int(fx["tokens"]))
+        exact_inputs.check(inp, fx)
+        assert np.array_equal(inp["T0"], fx["T0"])
+        _cache[name] = (fx, inp)
+    return _cache[name]
+
+
+def test_large_cases_present():
+    assert {"l128x2048_b4_k3", "l128x2048_b3_k3", "l128x2048_b4_k10", "l256x512_b2_k3", "h4096x4096_b4_k2"} <= set(LARGE)
+
+
+# ------------------------------------------------------------------------------------------ CPU oracle
+@pytest.mark.parametrize("name", [n for n in LARGE if not n.startswith("h")])
+def test_oracle_vs_reference_large(name):
+    from oracle import c_oracle
+
+    fx, inp = case(name)
+    K, V = int(fx["K"]), 2 ** int(fx["bits"])
+    Qs = exact_inputs.unpack_q_trace(fx)
+    WH = c_oracle.matmul(inp["W"], inp["H"])
+    for k in range(K):  # stage-wise: the reference's codebook in, the reference's indices / next codebook out
+        Q = c_oracle.solve_s(inp["W"], inp["L"], fx["T"][k])
+        assert np.array_equal(Q, Qs[k]), f"{name} iteration {k}: {(Q != Qs[k]).sum()} index mismatches vs the reference"
+        assert exact_inputs.sha(Q) == str(fx["sha_Q"][k])
+        assert rel_fro(c_oracle.update_t(WH, inp["H"], Qs[k], V), fx["T"][k + 1]) < TOL_T
+        d = c_oracle.quad_loss(inp["W"], inp["H"], fx["T"][k + 1], Qs[k])
+        assert abs(d - fx["dists"][k]) <= TOL_LOSS * abs(fx["dists"][k])
+    tr = c_oracle.run_layer_trace(inp["W"], inp["H"], inp["L"], inp["T0"], K)  # free-running
+    flips = [int((tr["Q_all"][k] != Qs[k]).sum()) for k in range(K)]
+    print(f"{name}: free-running index flips per iteration vs the reference: {flips}")
+    assert sum(flips) == 0
+    assert all(rel_fro(tr["T_all"][k], fx["T"][k + 1]) < TOL_T for k in range(K))
+    assert np.allclose(tr["dists"], fx["dists"], rtol=TOL_LOSS)
+    best = int(np.argmin(fx["dists"]))
+    Wq, Lo = c_oracle.dequant_losses(inp["W"], fx["T"][best + 1], Qs[K - 1], inp["hinv_diag"])
+    assert exact_inputs.sha(Wq) == str(fx["sha_Wq"])
+    assert abs(float(Lo.astype(np.float64).sum()) - float(fx["losses_sum"])) <= 1e-5 * float(fx["losses_sum"])
+
+
+def test_oracle_vs_reference_4096_hash_sampled_rows():
+    """CPU: 192 of the 4096 rows (rows are independent in the S-solve); the whole layer is the GPU test's"""
+    from oracle import c_oracle
+
+    fx, inp = case("h4096x4096_b4_k2")
+    rows = np.r_[0:64, 2000:2064, 4032:4096]
+    for k in range(int(fx["K"])):
+        Q = c_oracle.solve_s(inp["W"][rows], inp["L"], fx["T"][k][rows])
+        assert np.array_equal(exact_inputs.row_digest(Q), fx["Q_row_digest"][k][rows])
+
+
+# ------------------------------------------------------------------------------------------ HIP path
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from ganq_amd import _lib
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _lib.selftest()
+    return _lib
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", LARGE)
+def test_hip_vs_reference_large(hip, name):
+    fx, inp = case(name)
+    K, V, m = int(fx["K"]), 2 ** int(fx["bits"]), int(fx["m"])
+    hash_only = bool(fx["hash_only"])
+    Qs = None if hash_only else exact_inputs.unpack_q_trace(fx)
+    W, H, L = dev(inp["W"]), dev(inp["H"]), dev(inp["L"])
+    WH = hip.matmul_f32(W, H)
+    Q_ref_dev = []
+    for k in range(K):  # stage-wise against the reference
+        Qd = hip.solve_s(W, L, dev(fx["T"][k]))
+        Q = Qd.cpu().numpy()
+        if hash_only:
+            bad = int((exact_inputs.row_digest(Q) != fx["Q_row_digest"][k]).sum())
+            assert bad == 0, f"{name} iteration {k}: {bad} of {m} rows differ from the reference's indices"
+            assert exact_inputs.sha(Q) == str(fx["sha_Q"][k])
+        else:
+            assert np.array_equal(Q, Qs[k]), f"{name} iteration {k}: {(Q != Qs[k]).sum()} index mismatches vs the reference"
+        Q_ref_dev.append(Qd)  # == the reference's Q_k, just verified
+        T = hip.update_t(WH, H, Qd, V)
+        assert rel_fro(T.cpu().numpy(), fx["T"][k + 1]) < TOL_T
+        d = float(hip.quad_loss(W, H, dev(fx["T"][k + 1]), Qd).cpu())
+        assert abs(d - fx["dists"][k]) <= TOL_LOSS * abs(fx["dists"][k])
+    # free-running: the fused driver, K iterations on its own codebooks
+    rec = hip.run_layer_rows(W, H, L, dev(inp["T0"]), K, alias_q=True, want_q_all=True)
+    torch.cuda.synchronize()
+    flips = [int((rec["Q_all"][k] != Q_ref_dev[k]).sum()) for k in range(K)]
+    print(f"{name}: HIP free-running index flips per iteration vs the reference: {flips} of {m * int(fx['n'])}")
+    assert sum(flips) == 0
+    assert all(rel_fro(rec["T_all"][k].cpu().numpy(), fx["T"][k + 1]) < TOL_T for k in range(K))
+    assert np.allclose(rec["dists"].cpu().numpy(), fx["dists"], rtol=TOL_LOSS)
+    T, Q, dists, best_k = hip.run_layer(W, H, L, dev(inp["T0"]), K, alias_q=True)
+    assert int(best_k) == int(np.argmin(fx["dists"]))
+    assert exact_inputs.sha(Q.cpu().numpy()) == str(fx["sha_Q"][K - 1])
+    Wq, Lo = hip.dequant_losses(W, T, Q, dev(inp["hinv_diag"]))
+    assert rel_fro(Wq.cpu().numpy(), np.take_along_axis(fx["T"][int(best_k) + 1], Q.cpu().numpy().astype(np.int64), axis=1)) < TOL_T
+    assert abs(float(Lo.double().sum()) - float(fx["losses_sum"])) <= 1e-4 * float(fx["losses_sum"])
