@@ -218,37 +218,134 @@ def allgather_rows(local: torch.Tensor, slices: List[Tuple[int, int]], dim: int,
     return torch.cat([parts[r].narrow(dim, 0, b - a) for r, (a, b) in enumerate(slices)], dim=dim)
 
 
+class _Timer:
+    """wall time of the exchange steps, only when the caller asks for it (a synchronize on both sides of every
+    collective would otherwise serialise the host with the device)"""
+
+    def __init__(self, stats, device):
+        self.stats, self.on = stats, bool(stats is not None and stats.get("timing"))
+        self.device = device
+
+    def __call__(self, key):
+        return _TimerCtx(self, key)
+
+
+class _TimerCtx:
+    def __init__(self, t, key):
+        self.t, self.key = t, key
+
+    def __enter__(self):
+        if self.t.on:
+            import time
+
+            if self.t.device is not None and self.t.device.type == "cuda":
+                torch.cuda.synchronize(self.t.device)
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.t.on:
+            import time
+
+            if self.t.device is not None and self.t.device.type == "cuda":
+                torch.cuda.synchronize(self.t.device)
+            self.t.stats[self.key] = self.t.stats.get(self.key, 0.0) + time.perf_counter() - self.t0
+
+
 def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: float = -1.0, dist: Optional[Dist] = None,
-                          solver=None):
-    """ganq.py:516-634 with the rows of W split over the ranks.  Every rank passes the FULL W / T0 (replicated) and
-    gets the FULL (T_best, Q, dists, best_k) back.
+                          solver=None, t0_fn=None, stats: Optional[dict] = None):
+    """ganq.py:501-634 with the rows of W split over the ranks.  Every rank passes the FULL W (replicated) and gets the
+    FULL (T_best, Q, dists, best_k) back.  T0: the full initial codebook (replicated), or None with
+    `t0_fn(W_rows) -> T0_rows`: then the codebook initialisation (ganq.py:423-438, rows are independent) is sharded as
+    well -- every rank clusters its own rows only and the initial codebook is never exchanged.
 
     Each rank runs the FUSED loop (ganq_run_layer_rows: incremental bucket sums, closed-form loss, packed L -- the same
     kernels as the single-GPU path) on its row slice with no collective inside; afterwards ONE all-gather of the K x m
     per-row losses lets every rank form the K distances in the single-GPU summation order (ganq_select_best), so the
     best-of-K decision (ganq.py:621-626) and every returned bit equal the unsharded run's; then one all-gather of the
-    chosen codebook rows and one of the index rows."""
+    chosen codebook rows and one of the index rows.
+    stats: optional dict; with stats["timing"] set, "kmeans_s" / "loop_s" / "collective_s" are added up in it."""
     dist = dist or Dist.current()
     solver = solver or HipSolver()
     m, n = W.shape
-    V = T0.shape[1]
+    timer = _Timer(stats, W.device)
     # 128-row alignment keeps the per-128-row decisions of the W @ H kernel identical to the unsharded run
     slices = row_slices(m, dist.world, align=128 if m >= 128 * dist.world else 16)
     lo, hi = slices[dist.rank]
+    V = None if T0 is None else T0.shape[1]
     if hi > lo:
-        rec = solver.run_layer_rows(W[lo:hi].contiguous(), H, L, T0[lo:hi].contiguous(), K, alias_q, rcond)
+        W_loc = W[lo:hi].contiguous()
+        with timer("kmeans_s"):
+            T0_loc = T0[lo:hi].contiguous() if T0 is not None else t0_fn(W_loc)
+        V = T0_loc.shape[1]
+        with timer("loop_s"):
+            rec = solver.run_layer_rows(W_loc, H, L, T0_loc, K, alias_q, rcond)
         loss_loc, T_all, Q_last, Q_all = rec["loss_rows_all"], rec["T_all"], rec["Q_last"], rec["Q_all"]
     else:
+        if V is None:  # a rank without rows still needs the codebook width: cluster one row
+            V = t0_fn(W[:1].contiguous()).shape[1]
         loss_loc = torch.zeros((K, 0), dtype=torch.float64, device=W.device)
-        T_all = torch.zeros((K, 0, V), dtype=T0.dtype, device=W.device)
+        T_all = torch.zeros((K, 0, V), dtype=torch.float32, device=W.device)
         Q_last = torch.zeros((0, n), dtype=torch.uint8, device=W.device)
         Q_all = None if alias_q else torch.zeros((K, 0, n), dtype=torch.uint8, device=W.device)
-    loss_all = allgather_rows(loss_loc, slices, 1, dist)  # K x m doubles: the only exchange the decision needs
+    with timer("collective_s"):
+        loss_all = allgather_rows(loss_loc, slices, 1, dist)  # K x m doubles: the only exchange the decision needs
     dists, best_k_t = solver.select_best(loss_all)
     best_k = int(best_k_t)
     kk = best_k if best_k >= 0 else K - 1  # no iteration won (all NaN): the last codebook, like the single-GPU loop
     T_loc = T_all[kk]
     Q_loc = Q_last if (alias_q or best_k < 0) else Q_all[kk]
-    T_full = allgather_rows(T_loc.contiguous(), slices, 0, dist)
-    Q_full = allgather_rows(Q_loc.contiguous(), slices, 0, dist)
+    with timer("collective_s"):
+        T_full = allgather_rows(T_loc.contiguous(), slices, 0, dist)
+        Q_full = allgather_rows(Q_loc.contiguous(), slices, 0, dist)
     return T_full, Q_full, dists, best_k
+
+
+def reduce_group_statistics(tasks, dist: Dist, stats: Optional[dict] = None) -> None:
+    """Data-parallel calibration (SURVEY 8(e) axis 1): every rank forwarded ITS share of the calibration sequences and
+    holds, per hooked task, the partial Hessian H_r = (2/N_r) sum_{b in r} X_b^T X_b (gptq.py:122-131) with its own
+    sample count N_r.  The full statistic is the sample-weighted sum, H = sum_r (N_r / N) H_r: one all-reduce of the
+    counters, then one of n^2 floats per task (64 MiB at n = 4096).  Afterwards every rank holds the same H, nsamples
+    and fwd_counter -- the looper's "was this module ever invoked" decision (module_looper.py:332-343) included."""
+    if dist.world <= 1 or not tasks:
+        return
+    dev = dist.device or torch.device("cpu")
+    timer = _Timer(stats, dev)
+    local = torch.tensor([[t.fwd_counter, t.nsamples] for t in tasks], dtype=torch.float64, device=dev)
+    total = local.clone()
+    with timer("collective_s"):
+        allreduce_sum(total)
+    for i, t in enumerate(tasks):
+        n_loc, n_all = int(local[i, 1]), int(total[i, 1])
+        if n_all == 0:
+            t.fwd_counter = 0
+            continue
+        if hasattr(t, "H"):
+            H = t.hessian  # flushes the staged batches
+            H.mul_(n_loc / n_all)
+        else:
+            H = torch.zeros((t.columns, t.columns), dtype=torch.float32, device=t.device)
+        with timer("collective_s"):
+            allreduce_sum(H)
+        t.H, t.nsamples, t.fwd_counter = H, n_all, int(total[i, 0])
+
+
+def broadcast_calibration_batch(x: Optional[torch.Tensor], owner: int, dist: Dist, like_dtype=None) -> Optional[torch.Tensor]:
+    """north-star variant of the exchange: the rank that forwarded a calibration batch broadcasts the activations entering
+    a hooked module; every rank then accumulates the SAME batches in the SAME order as a single-GPU run, so the Hessian
+    -- and everything after it -- is bit-identical to world = 1.  x is None on the receivers (and on the owner when the
+    module was not invoked for this batch: then None comes back everywhere)."""
+    dev = dist.device or torch.device("cpu")
+    codes = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+    meta = torch.zeros(6, dtype=torch.int64, device=dev)
+    if dist.rank == owner and x is not None:
+        shp = list(x.shape)
+        meta[0], meta[1], meta[5] = 1, len(shp), codes[x.dtype]
+        for i, d in enumerate(shp[:3]):
+            meta[2 + i] = d
+    broadcast_tensor(meta, owner)
+    if int(meta[0]) == 0:
+        return None
+    shape = tuple(int(v) for v in meta[2:2 + int(meta[1])])
+    dtype = {v: k for k, v in codes.items()}[int(meta[5])]
+    buf = x.contiguous() if dist.rank == owner else torch.empty(shape, dtype=dtype, device=dev)
+    return broadcast_tensor(buf, owner)

@@ -74,7 +74,8 @@ class GPTQProcessor:
             "ganq_outliers": getattr(g, "ganq_outliers", None),
         }
         module.state.update({"wq": wq, "ganq_q": g.ganq_indices, "ganq_lut": g.ganq_codebook,
-                             "quant_time": time.time() - t0, "avg_loss": avg_loss})
+                             "quant_time": time.time() - t0, "avg_loss": avg_loss,
+                             "ganq_stats": {k: v for k, v in getattr(g, "ganq_stats", {}).items() if isinstance(v, float)}})
         g.free()
         del self.tasks[module.name]
         module.weight.data = wq  # the next modules / layers are calibrated on the quantized weight

@@ -8,9 +8,21 @@ after the last group, re-run the batches through the now-quantized layer to prod
 (module_looper.py:354-396).  Unlike the reference, activations never bounce through host memory
 (module_looper.py:289-302).
 
-With torch.distributed initialised, the modules of a group -- which share their calibration inputs -- are
-dealt to the ranks (ganq_amd.distributed.assign) and their results broadcast back, so every rank continues
-with identical quantized layers ("looper dispatches layers over RCCL ranks").
+With torch.distributed initialised ("looper dispatches layers over RCCL ranks") the default is
+`dist_mode="rows"`: BOTH axes on which the path shards are used, for every module of every group --
+  * calibration is data-parallel: rank r forwards the calibration batches b = r (mod world) through its replica of the
+    layer (the layer's outputs, i.e. the next layer's inputs, stay with the rank that produced them);
+    `calibration="allreduce"` (default): every rank accumulates a partial Hessian over its batches and the group's
+    statistics meet in ONE all-reduce of n^2 floats (ganq_amd.distributed.reduce_group_statistics);
+    `calibration="broadcast"` (the variant BASELINE.json's north star names): the forwarding rank broadcasts the
+    activations entering the hooked module and every rank accumulates all batches in single-GPU order -- 33x the bytes
+    at n = 4096, but every bit of the result equals the single-GPU run's;
+  * the quantization of a module is row-parallel: k-means, S-solve and T-update of rank r's row slice, one exchange of
+    the K x m row losses for best-of-K, one all-gather of the chosen codebook rows / indices
+    (GANQ.row_dist -> ganq_amd.distributed.run_layer_row_sharded).  The prologue (two factorisations) is replicated.
+`dist_mode="modules"` is the coarser scheme of round 1: the modules of a group are dealt to the ranks
+(ganq_amd.distributed.assign), every rank forwards everything, owners broadcast their results.
+Either way every rank ends with identical quantized layers.
 """
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -33,10 +45,23 @@ def find_modules(layer: nn.Module, names: Sequence[str]) -> Dict[str, nn.Module]
     return {n: named[n] for n in names if n in named}
 
 
+def _result_tensors(processor, named_module):
+    """the device tensors a finished module leaves behind (weight, indices, codebook, compat values, outliers)"""
+    out = []
+    res = processor.results().get(named_module.full_name, {})
+    vals = list(res.values()) + [named_module.state.get("wq")]
+    for v in vals:
+        for t in (v if isinstance(v, (tuple, list)) else (v,)):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                out.append(t)
+    return out
+
+
 class ModuleLooper:
     def __init__(self, processor, layers: Sequence[nn.Module], layer_modules: List[List[str]],
                  layers_prefix: str = "model.layers", share_group_hessian: bool = False, early_exit: bool = True,
-                 cache_outputs: bool = True, cache_budget_bytes: int = 48 << 30, concurrent_group: bool = True):
+                 cache_outputs: bool = True, cache_budget_bytes: int = 48 << 30, concurrent_group: bool = True,
+                 dist_mode: str = "rows", calibration: str = "allreduce"):
         # share_group_hessian: the modules of one group ([q,k,v], [gate,up]) receive the same inputs, so the first
         # one accumulates the Hessian and runs the prologue (permutation, factor, damping) for all of them; the
         # reference does both once per module.  Same numbers, less work.  Only valid when the groups really share
@@ -60,6 +85,11 @@ class ModuleLooper:
         # of a group are independent given the prologue.  Same numbers: every module's work is the same sequence of
         # launches on its own stream.
         self.concurrent_group = concurrent_group
+        # multi-GPU scheme (module docstring); ignored when torch.distributed is not initialised
+        if dist_mode not in ("rows", "modules", "none") or calibration not in ("allreduce", "broadcast"):
+            raise ValueError(f"ModuleLooper: dist_mode={dist_mode!r} / calibration={calibration!r}")
+        self.dist_mode, self.calibration = dist_mode, calibration
+        self.dist_stats = {"timing": False}  # set ["timing"] = True to have the exchange steps timed (adds synchronisation)
         self.processor = processor
         self.layers = layers
         self.layer_modules = layer_modules
@@ -81,18 +111,30 @@ class ModuleLooper:
 
         main = torch.cuda.current_stream(dev)
         errors, threads, streams = [], [], []
+        log_rows = {}  # processor.log rows per module, re-assembled in `todo` order after the join
+        log_before = len(self.processor.log)
 
         def run(n, stream):
             try:
-                with torch.cuda.device(dev), torch.cuda.stream(stream):
+                # grad mode is thread-local: the caller's no_grad() does not reach a worker thread
+                with torch.no_grad(), torch.cuda.device(dev), torch.cuda.stream(stream):
                     self.processor.process(named[n])
+                    # the follower's results were allocated under its side stream and are read (and freed) under the
+                    # main stream from here on: tell the caching allocator
+                    for t in _result_tensors(self.processor, named[n]):
+                        t.record_stream(main)
             except BaseException as e:  # re-raised on the caller's thread
                 errors.append(e)
 
         def start_followers():
+            shared = getattr(tasks[followers[0]], "_leader_prologue", None) or {}
             for n in followers:
                 st = torch.cuda.Stream(device=dev)
                 st.wait_stream(main)  # the shared prologue was enqueued on the leader's stream
+                # ... and allocated under it: a block the leader drops must not be reused while a side stream reads it
+                for t in shared.values():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(st)
                 th = threading.Thread(target=run, args=(n, st), name=f"ganq-{n}")
                 streams.append(st)
                 threads.append(th)
@@ -109,18 +151,38 @@ class ModuleLooper:
         if followers and not threads:  # the leader never reached the hand-over (it keeps its hook only while it lives)
             for n in followers:
                 self.processor.process(named[n])
+        # the worker threads appended their log rows in completion order: restore the group's module order
+        new_rows = self.processor.log[log_before:]
+        for row in new_rows:
+            log_rows.setdefault(row.get("module"), []).append(row)
+        ordered = [r for n in todo for r in log_rows.pop(n, [])] + [r for rows in log_rows.values() for r in rows]
+        self.processor.log[log_before:] = ordered
         if errors:
             raise errors[0]
 
     @torch.no_grad()
     def loop(self, layer_inputs: List[torch.Tensor], layer_kwargs: Optional[List[dict]] = None,
-             forward: Optional[Callable] = None, progress: Optional[Callable] = None):
+             forward: Optional[Callable] = None, progress: Optional[Callable] = None, inputs_are_local: bool = False):
         """layer_inputs: hidden states entering layer 0, one tensor per calibration batch ([b, seq, hidden]);
         layer_kwargs: per-batch keyword arguments of the layer forward (attention mask, position ids, ...).
-        Returns the hidden states leaving the last layer."""
+        Returns the hidden states leaving the last layer.
+        Several ranks, dist_mode="rows": rank r works on the batches r, r + world, ... -- pass all batches (every rank
+        picks its own) or, with inputs_are_local=True, only those; the returned list holds the rank's own batches."""
         layer_kwargs = layer_kwargs or [{} for _ in layer_inputs]
         fwd = forward or (lambda layer, x, kw: layer(x, **kw))
-        dist = gdist.Dist.current()
+        # dist_mode="none": this process quantizes on its own even if torch.distributed is initialised (A/B runs)
+        dist = gdist.Dist.current() if self.dist_mode != "none" else gdist.Dist(0, 1, None)
+        sharded = dist.world > 1 and self.dist_mode == "rows"
+        n_global = len(layer_inputs)
+        if sharded:
+            if inputs_are_local:
+                cnt = torch.tensor([len(layer_inputs)], dtype=torch.float64, device=dist.device or "cpu")
+                n_global = int(gdist.allreduce_sum(cnt))
+                if len(layer_inputs) != len(range(dist.rank, n_global, dist.world)):
+                    raise ValueError("ModuleLooper: with inputs_are_local the ranks must hold the batches r, r + world, ...")
+            else:
+                layer_inputs = list(layer_inputs[dist.rank::dist.world])
+                layer_kwargs = list(layer_kwargs[dist.rank::dist.world])
         for li, layer in enumerate(self.layers):
             cur = {"batch": 0, "pass": 0}
             wrapped, cached_bytes = [], [0]
@@ -153,16 +215,24 @@ class ModuleLooper:
                     continue
                 named = {n: NamedModule(m, name=n, full_name=f"{self.layers_prefix}.{li}.{n}", layer_index=li)
                          for n, m in mods.items()}
-                owners = gdist.assign({n: (nm.state["out_features"], nm.state["in_features"])
-                                       for n, nm in named.items()}, dist.world)
+                if sharded:  # every rank works on every module (its share of the batches, its slice of the rows)
+                    owners = {n: dist.rank for n in named}
+                else:
+                    owners = gdist.assign({n: (nm.state["out_features"], nm.state["in_features"])
+                                           for n, nm in named.items()}, dist.world)
                 mine = [n for n in named if owners[n] == dist.rank]
                 handles = []
+                hooked_names = []
+                captured = {}  # calibration="broadcast": what the hooks of this rank saw in the current batch
                 leader = None  # the modules of a group see the same inputs: one Hessian / prologue for all of them
                 for n in mine:
                     self.processor.preprocess(named[n], buffered_fwd=False)
                     if self.processor.is_skipped(named[n]):
                         continue
                     task = self.processor.tasks[n]
+                    if sharded:
+                        task.row_dist = dist
+                        task.time_collectives = bool(self.dist_stats.get("timing"))
                     # a follower takes the leader's Hessian AND prologue: only when every setting the prologue depends on
                     # is the same (a `dynamic` override of damp_percent / act_sort for one module makes it its own leader)
                     if (self.share_group_hessian and leader is not None
@@ -171,7 +241,13 @@ class ModuleLooper:
                         continue
                     if leader is None:
                         leader = n
-                    handles.append(mods[n].register_forward_hook(self.processor.preprocess_fwd_hook(n)))
+                    hooked_names.append(n)
+                    if sharded and self.calibration == "broadcast":
+                        def capture_hook(_mod, inp, _out, _n=n):
+                            captured[_n] = inp[0].data
+                        handles.append(mods[n].register_forward_hook(capture_hook))
+                    else:
+                        handles.append(mods[n].register_forward_hook(self.processor.preprocess_fwd_hook(n)))
                 hooked, fired = len(handles), set()
                 if self.early_exit and hooked:
                     def stop_hook(mod, _inp, _out):
@@ -183,17 +259,34 @@ class ModuleLooper:
                             raise _StopForward
 
                     # registered after the statistics hooks, so it runs after them
-                    handles += [mods[n].register_forward_hook(stop_hook) for n in mine
-                                if not self.processor.is_skipped(named[n])
-                                and getattr(self.processor.tasks[n], "_group_leader", None) is None]
-                for bi, (x, kw) in enumerate(zip(layer_inputs, layer_kwargs)):
+                    handles += [mods[n].register_forward_hook(stop_hook) for n in hooked_names]
+
+                def forward_local(bi):
                     fired.clear()
                     cur["batch"] = bi
                     cur["pass"] += 1
                     try:
-                        fwd(layer, x, kw)
+                        fwd(layer, layer_inputs[bi], layer_kwargs[bi])
                     except _StopForward:
                         pass
+
+                if sharded and self.calibration == "broadcast":
+                    # every rank accumulates every batch, in the order a single GPU would: the rank that owns batch b
+                    # forwards it and broadcasts what entered each hooked module
+                    for b in range(n_global):
+                        owner = b % dist.world
+                        captured.clear()
+                        if owner == dist.rank:
+                            forward_local(b // dist.world)
+                        for n in hooked_names:
+                            x = gdist.broadcast_calibration_batch(captured.get(n), owner, dist)
+                            if x is not None:
+                                self.processor.tasks[n].add_batch(x, None)
+                else:
+                    for bi in range(len(layer_inputs)):
+                        forward_local(bi)
+                    if sharded:  # partial Hessians of the ranks' shares -> the group's statistics, on every rank
+                        gdist.reduce_group_statistics([self.processor.tasks[n] for n in hooked_names], dist, self.dist_stats)
                 for h in handles:
                     h.remove()
                 todo = []
@@ -212,13 +305,20 @@ class ModuleLooper:
                         self.processor.skip(named[n])
                         continue
                     todo.append(n)
-                self._process_group(todo, named)
+                if sharded:  # the row-sharded loop has collectives inside: one module after the other, in one order
+                    for n in todo:
+                        self.processor.process(named[n])
+                        for k, v in getattr(named[n], "state", {}).get("ganq_stats", {}).items():
+                            if k.endswith("_s"):
+                                self.dist_stats[k] = self.dist_stats.get(k, 0.0) + v
+                else:
+                    self._process_group(todo, named)
                 for n in todo:
                     if self.cache_outputs:
                         cache_module(mods[n])
                     if progress:
                         progress(named[n])
-                if dist.world > 1:
+                if dist.world > 1 and not sharded:
                     for n in named:  # owner broadcasts its result so every rank holds the quantized group
                         gdist.share_module_result(self.processor, named[n], owners[n], dist)
                         if self.cache_outputs and n not in mine:

@@ -70,7 +70,13 @@ def quantize_model(model: nn.Module, calibration: Sequence[torch.Tensor], qcfg: 
     lm = layer_map or layer_map_for(model)
     layers = _get_module(model, lm.layers_node)
     dev = next(model.parameters()).device
-    batches = [b.to(dev) for b in calibration]
+    from .. import distributed as gdist
+
+    dist = gdist.Dist.current()
+    # several ranks, dist_mode="rows" (the default): calibration is data-parallel -- this rank embeds and forwards only the
+    # batches rank, rank + world, ...
+    local = dist.world > 1 and looper_options.get("dist_mode", "rows") == "rows"
+    batches = [b.to(dev) for b in (calibration[dist.rank::dist.world] if local else calibration)]
     was_training = model.training
     model.eval()
     hidden, kwargs_list = capture_layer_inputs(model, layers, batches)
@@ -81,7 +87,7 @@ def quantize_model(model: nn.Module, calibration: Sequence[torch.Tensor], qcfg: 
         return layer(x, **kw)
 
     ModuleLooper(proc, layers, lm.layer_modules, layers_prefix=lm.layers_node, **looper_options).loop(
-        hidden, kwargs_list, forward=fwd, progress=progress)
+        hidden, kwargs_list, forward=fwd, progress=progress, inputs_are_local=local)
     proc.finalize(model)
     model.quantize_config = qcfg
     model.train(was_training)

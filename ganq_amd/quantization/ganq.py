@@ -33,6 +33,9 @@ class GANQ(GPTQ):
         self.ganq_codebook = None
         self.ganq_outliers = None  # CSR (rowptr int32 [m+1], cols int32 [nnz], vals fp32 [nnz]) when the split is on
         self.ganq_stats = {}
+        # set by the looper when torch.distributed runs this module's rows over several GPUs (SURVEY 8(e) axis 2): a
+        # ganq_amd.distributed.Dist with world > 1.  Every rank must then call quantize() on the same statistics.
+        self.row_dist = None
 
     def _needs_only_hinv_diag(self) -> bool:
         return True
@@ -65,10 +68,23 @@ class GANQ(GPTQ):
         if ratio > 0.0:  # W becomes W_dense in place (it is this call's private fp32 copy, gptq.py:77-86)
             rowptr, cols, vals, _ = _lib.outlier_split(W, ratio)
             sparse = (rowptr, cols, vals)
-        T0 = self._initialize_codebook_kmeans(W, Hinv, num_bits, W.device)
-        assert T0.shape == (W.shape[0], V)
         alias = bool(getattr(self.qcfg, "ganq_reference_q_alias", True))
-        T, Q, dists, best_k = _lib.run_layer(W, self.Xxt_damped, self.L, T0, self.iterations, alias_q=alias)
+        rd = self.row_dist
+        if rd is not None and rd.world > 1:
+            # rows of W are independent in the codebook initialisation, the S-solve and the T-update; only best-of-K
+            # looks at all of them: each rank clusters and iterates its own rows, one exchange of K x m row losses
+            # decides, one all-gather each brings the chosen codebook rows and the indices to every rank
+            from .. import distributed as gdist
+
+            stats = {"timing": bool(getattr(self, "time_collectives", False))}
+            T, Q, dists, best_k = gdist.run_layer_row_sharded(
+                W, self.Xxt_damped, self.L, None, self.iterations, alias_q=alias, dist=rd, stats=stats,
+                t0_fn=lambda W_rows: self._initialize_codebook_kmeans(W_rows, Hinv, num_bits, W.device))
+            self.ganq_stats.update({k: v for k, v in stats.items() if k != "timing"})
+        else:
+            T0 = self._initialize_codebook_kmeans(W, Hinv, num_bits, W.device)
+            assert T0.shape == (W.shape[0], V)
+            T, Q, dists, best_k = _lib.run_layer(W, self.Xxt_damped, self.L, T0, self.iterations, alias_q=alias)
         Wq, Losses = _lib.dequant_losses(W, T, Q, _hinv_diag(Hinv).contiguous())
         if sparse is not None:  # effective weight = dequantised dense part + the exact outliers
             rowptr, cols, vals = sparse
@@ -77,7 +93,7 @@ class GANQ(GPTQ):
             self.ganq_outliers = sparse
         self.ganq_indices = Q          # permuted column order until quantize() un-permutes it
         self.ganq_codebook = T
-        self.ganq_stats = {"dists": dists, "best_k": best_k, "enqueue_s": time.perf_counter() - t0}
+        self.ganq_stats.update({"dists": dists, "best_k": best_k, "enqueue_s": time.perf_counter() - t0})
 
         if not scale:  # "Unused, compatibility with interface" (ganq.py:640-644)
             self.quantizer.find_params(W, weight=True)

@@ -307,7 +307,9 @@ class GPTQ:
 
         Q, Losses, scale, zero = self._perform_quantization_loop(W, Hinv, blocksize, perm, invperm)
 
-        torch.cuda.synchronize(self.device)
+        # the reference synchronises the device here (gptq.py:324); this module's work is all on the current stream, and a
+        # device-wide wait would make a follower on a side stream wait for its leader's whole loop
+        torch.cuda.current_stream(self.device).synchronize()
         avg_loss = torch.sum(Losses).item() / self.nsamples
         if math.isnan(avg_loss):
             raise ValueError("Quantization: Failed due to `NaN` loss")

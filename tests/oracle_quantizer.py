@@ -23,6 +23,24 @@ from ganq_amd.quantization.quantizer import Quantizer
 from oracle import c_oracle
 
 
+class OracleSolver:
+    """CPU stand-in for ganq_amd.distributed.HipSolver (same two methods): the collective logic of
+    run_layer_row_sharded is exercised under gloo with the oracle serving the per-slice loop"""
+
+    def run_layer_rows(self, W, H, L, T0, K, alias_q, rcond):
+        tr = c_oracle.run_layer_trace(W.numpy(), H.numpy(), L.numpy(), T0.numpy(), K, rcond)
+        return dict(T_all=torch.from_numpy(tr["T_all"]), loss_rows_all=torch.from_numpy(tr["loss_rows_all"]),
+                    Q_last=torch.from_numpy(tr["Q_all"][K - 1].copy()), Q_all=None if alias_q else torch.from_numpy(tr["Q_all"]))
+
+    def select_best(self, loss_rows_all):
+        d = loss_rows_all.sum(dim=1)  # the HIP library sums in its own fixed order; any fixed order serves the CPU test
+        best, bk = float("inf"), -1
+        for k in range(d.shape[0]):  # ganq.py:625: strict <, first minimum
+            if float(d[k]) < best:
+                best, bk = float(d[k]), k
+        return d, torch.tensor(bk, dtype=torch.int32)
+
+
 class OracleGANQ:
     def __init__(self, module, qcfg):
         self.module = module.module
@@ -36,6 +54,12 @@ class OracleGANQ:
         self.quantizer = Quantizer(qcfg=qcfg, name=module.name)
         self.iterations = qcfg.ganq_iterations
         self.ganq_indices = self.ganq_codebook = self.ganq_outliers = None
+        self.row_dist = None  # set by the looper: rows over the ranks (ganq_amd.distributed.run_layer_row_sharded)
+        self.ganq_stats = {}
+
+    @property
+    def hessian(self):
+        return self.H
 
     # gptq.py:88-131
     def add_batch(self, inp, out):
@@ -91,9 +115,17 @@ class OracleGANQ:
         V = 2 ** c.bits
         weights = (hd ** (-4)).double().numpy()
         Wn = W.numpy()
-        T0 = c_oracle.kmeans_init(Wn, weights, V)
         alias = bool(getattr(c, "ganq_reference_q_alias", True))
-        T, Q, dists, best_k = c_oracle.run_layer(Wn, Xxt_damped.numpy(), L.numpy(), T0, self.iterations, alias_q=alias)
+        if self.row_dist is not None and self.row_dist.world > 1:
+            from ganq_amd import distributed as gdist
+
+            Tt, Qt, _, _ = gdist.run_layer_row_sharded(
+                W, Xxt_damped, L, None, self.iterations, alias_q=alias, dist=self.row_dist, solver=OracleSolver(),
+                t0_fn=lambda Wr: torch.from_numpy(c_oracle.kmeans_init(Wr.numpy(), weights, V)))
+            T, Q = Tt.numpy(), Qt.numpy()
+        else:
+            T0 = c_oracle.kmeans_init(Wn, weights, V)
+            T, Q, dists, best_k = c_oracle.run_layer(Wn, Xxt_damped.numpy(), L.numpy(), T0, self.iterations, alias_q=alias)
         Wq, Losses = c_oracle.dequant_losses(Wn, T, Q, hd.numpy())
         avg_loss = float(Losses.astype(np.float64).sum()) / self.nsamples
         group_size = c.group_size if c.group_size != -1 else self.columns

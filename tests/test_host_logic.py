@@ -87,27 +87,8 @@ def test_assign_and_row_slices():
         assert all((a % 16 == 0) for a, _ in sl if a < m)
 
 
-class OracleSolver:
-    """CPU stand-in for HipSolver (same two methods), for the gloo tests only: the collective logic of
-    run_layer_row_sharded is exercised with the oracle serving the per-slice loop"""
-
-    def __init__(self):
-        from oracle import c_oracle
-
-        self.o = c_oracle
-
-    def run_layer_rows(self, W, H, L, T0, K, alias_q, rcond):
-        tr = self.o.run_layer_trace(W.numpy(), H.numpy(), L.numpy(), T0.numpy(), K, rcond)
-        return dict(T_all=torch.from_numpy(tr["T_all"]), loss_rows_all=torch.from_numpy(tr["loss_rows_all"]),
-                    Q_last=torch.from_numpy(tr["Q_all"][K - 1].copy()), Q_all=None if alias_q else torch.from_numpy(tr["Q_all"]))
-
-    def select_best(self, loss_rows_all):
-        d = loss_rows_all.sum(dim=1)  # the HIP library sums in its own fixed order; any fixed order serves the CPU test
-        best, bk = float("inf"), -1
-        for k in range(d.shape[0]):  # ganq.py:625: strict <, first minimum
-            if float(d[k]) < best:
-                best, bk = float(d[k]), k
-        return d, torch.tensor(bk, dtype=torch.int32)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle_quantizer import OracleSolver  # noqa: E402
 
 
 def _golden(name):
@@ -181,3 +162,94 @@ def test_backend_registration_selects_the_lut_layer():
         select_quant_linear(8, 128, True, True, format=FORMAT.GANQ_LUT)
     with pytest.raises(ValueError):
         select_quant_linear(4, 128, True, True, backend=BACKEND.GANQ_HIP, format=FORMAT.FAKE)
+
+
+# ------------------------------------------------------------------------------------------ the looper over two ranks
+def _tiny_model(seed=0):
+    import torch.nn as nn
+
+    class Blk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj = nn.Linear(64, 64, bias=False), nn.Linear(64, 32, bias=False), nn.Linear(64, 32, bias=False)
+            self.o_proj = nn.Linear(64, 64, bias=False)
+
+        def forward(self, x):
+            h = self.q_proj(x) + torch.cat([self.k_proj(x), self.v_proj(x)], -1)
+            return x + self.o_proj(torch.tanh(h))
+
+    torch.manual_seed(seed)
+    return [Blk(), Blk()]
+
+
+def _tiny_inputs():
+    g = torch.Generator().manual_seed(5)
+    scale = 0.2 + torch.rand(64, generator=g)
+    return [torch.randn(2, 24, 64, generator=g) * scale for _ in range(5)]  # 5 batches: uneven shares over two ranks
+
+
+def _run_looper(calibration, dist_mode):
+    from ganq_amd.looper.module_looper import ModuleLooper
+    from oracle_quantizer import OracleProcessor
+
+    layers = _tiny_model()
+    proc = OracleProcessor(QuantizeConfig(bits=3, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=2))
+    looper = ModuleLooper(proc, layers, [["q_proj", "k_proj", "v_proj"], ["o_proj"]], layers_prefix="layers",
+                          dist_mode=dist_mode, calibration=calibration)
+    outs = looper.loop(_tiny_inputs())
+    res = {k: (v["ganq_q"].numpy().copy(), v["ganq_lut"].numpy().copy()) for k, v in proc.results().items()}
+    return res, [o.numpy().copy() for o in outs], [dict(r) for r in proc.log]
+
+
+def _looper_worker(rank, world, port, calibration, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import torch.distributed as td
+
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import c_oracle
+
+        c_oracle.set_num_threads(1)
+        out_q.put((rank,) + _run_looper(calibration, "rows"))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("calibration", ["broadcast", "allreduce"])
+def test_looper_rows_mode_two_ranks_gloo(calibration):
+    """ModuleLooper(dist_mode="rows") over two gloo ranks with the CPU oracle in the quantizer slot: data-parallel calibration
+    (ranks forward batches 0,2,4 / 1,3), Hessian exchange, row-sharded k-means + loop, un-hit bookkeeping.  With
+    calibration="broadcast" every bit equals the single-process run; with "allreduce" the ranks agree with each other and
+    with the single-process run up to the rounding of the summed Hessian."""
+    from oracle import c_oracle
+
+    torch.set_num_threads(1)
+    c_oracle.set_num_threads(1)
+    base, base_outs, base_log = _run_looper("allreduce", "none")
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = 29300 + (os.getpid() % 200) + (7 if calibration == "broadcast" else 0)
+    procs = [ctx.Process(target=_looper_worker, args=(r, 2, port, calibration, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((out_q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, r0, o0, log0), (_, r1, o1, log1) = res
+    assert sorted(r0) == sorted(r1) == sorted(base) and len(base) == 8
+    assert [(r["layer"], r["module"]) for r in log0] == [(r["layer"], r["module"]) for r in base_log]
+    for name in base:
+        assert np.array_equal(r0[name][0], r1[name][0]) and np.array_equal(r0[name][1], r1[name][1]), name  # ranks agree
+        if calibration == "broadcast":
+            assert np.array_equal(r0[name][0], base[name][0]) and np.array_equal(r0[name][1], base[name][1]), name
+        else:
+            assert (r0[name][0] != base[name][0]).mean() < 0.02, name
+            assert np.linalg.norm(r0[name][1] - base[name][1]) / np.linalg.norm(base[name][1]) < 1e-3, name
+    assert len(o0) == 3 and len(o1) == 2  # every rank keeps the outputs of its own batches
+    if calibration == "broadcast":
+        for got, want in zip(o0 + o1, [base_outs[i] for i in (0, 2, 4, 1, 3)]):
+            assert np.array_equal(got, want)
