@@ -16,16 +16,24 @@ group that shares one set of calibration activations (like q/k/v): rank 0 genera
 activations and broadcasts them over RCCL/xGMI during setup, every rank accumulates the Hessian with the HIP
 kernel and quantizes its layer (seed = rank).  The broadcast time is reported in `setup`.
 
-`--mode rows` (strong scaling): ONE layer whose rows are split over the ranks (ganq_amd.distributed.run_layer_row_sharded:
-the fused loop on each rank's slice, then one all-gather of the K x m per-row losses for the global best-of-K decision and
-one of the chosen rows); value = steps * 4096 / wall time -- the same layer however many GPUs work on it.
+`--mode rows` (strong scaling): ONE layer whose rows are split over the ranks; value = steps * 4096 / wall time -- the same
+layer however many GPUs work on it.  It times what a row-sharded module really costs every rank: a complete `quantize()` on the group's reduced
+Hessian -- prologue (two factorisations, replicated), k-means and the fused loop on the rank's row slice, the exchange of the
+row losses / chosen rows -- and reports the per-phase seconds of rank 0 (`setup.rows_phases`).  Calibration is data-parallel
+there: every rank accumulates the Hessian of ITS share of the sequences and the partial sums meet in one all-reduce
+(`setup.hessian_s`, `setup.allreduce_s`).  With more than one GPU the default mode adds the same measurement as the
+`row_sharded` object, so one line carries both the weak- and the strong-scaling figure.
 
 Besides the driver contract the JSON line carries `roofline` (dominant kernel of the timed region, measured live
 with HIP events on the launch stream; `achieved` counts the flops of the rows the launches really solved -- converged
 rows are skipped from the third iteration on), `cpu_baseline` (oracle/ganq_oracle.c on this host's cores on a bounded
 sample of the same workload, the torch restatement of the reference's own op sequence beside it) and `lut_forward`
 (BASELINE configs[2]: the LUT decode kernel against torch fp16 F.linear on the same shapes, device time from HIP-graph
-replays, weights hot in the Infinity Cache and cold from HBM).
+replays, weights hot in the Infinity Cache and cold from HBM), `opt125m` (BASELINE.json's target quantity: whole-model columns/s
+on the opt-125m architecture -- 72 linears, 128 x 2048 tokens, K = 10, forward passes included -- next to the C oracle's loop on
+the same module shapes) and `ppl` (Wiki2 perplexity through tools/eval_ppl.py when --model-path / --wikitext-path [/ --c4-path]
+or GANQ_MODEL_PATH / GANQ_WIKITEXT_PATH / GANQ_C4_PATH name local files; "unmeasured: ..." otherwise -- the boxes have no
+network).
 """
 import argparse
 import json
@@ -43,7 +51,8 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 INT8_MFMA_PEAK_TOPS = 5000.0    # MI355X_MICROARCH.md: i8 MFMA = 2x the bf16 rate per clock, bf16 dense ~2.5 PF
-PMC_FILE = "r02_pmc_traffic_v2.json"   # rocprofv3 --pmc summary of the loop's kernels at HEAD (tools/pmc_collect.sh)
+PMC_FILE = "r03_pmc_traffic.json"      # rocprofv3 --pmc summary of the loop's kernels (tools/pmc_collect.sh); carries the sha256
+                                       # of the kernel sources it was collected on -- other sources: traffic is reported as null
 
 
 def log(*a):
@@ -90,14 +99,21 @@ def build_workload(args, dist, dev):
 
     gs = torch.Generator(device="cpu").manual_seed(999)
     scale = (0.1 + torch.rand(n, generator=gs)).to(dev)
-    t_bcast = t_hess = 0.0
+    t_bcast = t_hess = t_allreduce = 0.0
+    data_parallel = getattr(args, "mode", "layers") == "rows" and dist.world > 1
     for b in range(args.nseq):
-        if dist.rank == 0:
+        if data_parallel:
+            # data-parallel calibration: rank r generates ("forwards") and accumulates only the sequences b = r (mod world)
+            if b % dist.world != dist.rank:
+                continue
+            gx = torch.Generator(device=dev).manual_seed(1000 + b)
+            x = (torch.randn(args.seqlen, n, generator=gx, device=dev) * scale).half()
+        elif dist.rank == 0:
             gx = torch.Generator(device=dev).manual_seed(1000 + b)
             x = (torch.randn(args.seqlen, n, generator=gx, device=dev) * scale).half()
         else:
             x = torch.empty((args.seqlen, n), dtype=torch.float16, device=dev)
-        if dist.world > 1:
+        if dist.world > 1 and not data_parallel:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             gdist.broadcast_tensor(x, 0)  # RCCL over xGMI: calibration activations to every owner rank
@@ -105,10 +121,17 @@ def build_workload(args, dist, dev):
             t_bcast += time.perf_counter() - t0
         t0 = time.perf_counter()
         q.add_batch(x.unsqueeze(0), None)  # one sequence per call, as the looper's forward hook does
-        if b == args.nseq - 1:
+        if b >= args.nseq - dist.world:
             torch.cuda.synchronize()
         t_hess += time.perf_counter() - t0
     torch.cuda.synchronize()
+    if data_parallel:  # the partial Hessians meet in ONE all-reduce of n^2 floats (RCCL over xGMI)
+        q.hessian  # flush the staged batches outside the timer
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gdist.reduce_group_statistics([q], dist)
+        torch.cuda.synchronize()
+        t_allreduce = time.perf_counter() - t0
     H_copy, n_copy = q.hessian.clone(), q.nsamples
     t0 = time.perf_counter()
     wq, _, _, _, _, avg_loss, damp = q.quantize()  # full quantize(): prologue + k-means + loop + epilogue
@@ -123,10 +146,48 @@ def build_workload(args, dist, dev):
     q2.quantize()
     torch.cuda.synchronize()
     t_full_warm = time.perf_counter() - t0
-    setup = {"hessian_s": round(t_hess, 4), "xgmi_broadcast_s": round(t_bcast, 4), "kmeans_s": round(captured["kmeans_s"], 4),
+    captured.update(lin=lin, qcfg=qcfg, H_raw=H_copy, nsamples=n_copy)
+    setup = {"hessian_s": round(t_hess, 4), "xgmi_broadcast_s": round(t_bcast, 4), "allreduce_s": round(t_allreduce, 4), "kmeans_s": round(captured["kmeans_s"], 4),
              "full_quantize_s": round(t_full, 4), "full_quantize_warm_s": round(t_full_warm, 4), "avg_loss": avg_loss, "damp_percent": damp,
              "calib_bytes": args.nseq * args.seqlen * n * 2}
     return captured, setup
+
+
+def host_cores():
+    """CPU threads this process may really use: the smallest of os.cpu_count(), the scheduler affinity mask and the cgroup
+    CPU quota (a GPU box hands a one-GPU job a share of a many-core host; running one OpenMP thread per core of the WHOLE host
+    inside that share only makes the baseline slower) -> (threads, detail dict)"""
+    detail = {"os_cpu_count": os.cpu_count()}
+    n = os.cpu_count() or 1
+    try:
+        detail["sched_affinity"] = len(os.sched_getaffinity(0))
+        n = min(n, detail["sched_affinity"])
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                detail["cgroup_cpu_quota"] = round(float(quota) / period, 2)
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), detail
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cap, args):
@@ -136,7 +197,8 @@ def cpu_baseline(cap, args):
     lstsq/gelsd, quad loss), which is what a user of the reference runs."""
     from oracle import c_oracle, ganq_ref
 
-    threads = max(1, min(os.cpu_count() or 1, 16))
+    threads, core_detail = host_cores()  # BASELINE.md section 3: the box's own host cores, count stated
+    log(f"[bench] cpu_baseline on {threads} threads ({core_detail})")
     torch.set_num_threads(threads)
     rows = min(args.cpu_rows, args.m)
     W = cap["W"][:rows].cpu()
@@ -158,11 +220,112 @@ def cpu_baseline(cap, args):
     t0 = time.perf_counter()
     c_oracle.run_layer(Wn, Hn, Ln, Tn, 1)
     t_c = time.perf_counter() - t0
+    extra = {}
+    if threads > 16:  # rounds 1-2 capped the baseline at 16 threads: kept beside the all-core figure for continuity
+        c_oracle.set_num_threads(16)
+        t0 = time.perf_counter()
+        c_oracle.run_layer(Wn, Hn, Ln, Tn, 1)
+        t16 = time.perf_counter() - t0
+        c_oracle.set_num_threads(threads)
+        extra["c_oracle_16_threads"] = {"value": round(args.n / (t16 * (args.m / rows_c) * args.iters), 4), "cores": 16,
+                                         "measured_s": round(t16, 3)}
     return {"value": round(args.n / (t_c * (args.m / rows_c) * args.iters), 4), "unit": "columns/s", "cores": threads,
-            "kind": "port",
+            "cpu_count": os.cpu_count(), "cores_detail": core_detail, "cpu_model": _cpu_model(), "torch": torch.__version__, "ganq_iterations": args.iters,
+            **extra, "kind": "port",
             "sample": f"oracle/ganq_oracle.c (OpenMP, {threads} threads), {rows_c} of {args.m} rows x 1 of {args.iters} iterations "
                       f"of the same {args.m}x{args.n} layer, {t_c:.2f} s measured, scaled by rows and iterations",
             "measured_s": round(t_c, 3), "torch_op_sequence": torch_seq}
+
+
+def make_sharded_quantize(cap, dist):
+    """-> step(timing=False): one complete GANQ.quantize() of the layer on the (already reduced) Hessian with the rows split
+    over the ranks (GANQ.row_dist): prologue replicated, k-means + fused loop on the rank's slice, exchange of the row
+    losses / chosen rows.  Returns the quantizer (its ganq_stats carry the phase seconds when timing is on)."""
+    from ganq_amd.looper.named_module import NamedModule
+    from ganq_amd.quantization import GANQ
+
+    def step(timing=False):
+        q = GANQ(NamedModule(cap["lin"], "proj", "model.layers.0.proj0", 0), cap["qcfg"])
+        q.quantizer.configure(perchannel=True)
+        q.H, q.nsamples = cap["H_raw"].clone(), cap["nsamples"]
+        q.row_dist, q.time_collectives = dist, timing
+        q.fwd_counter = 1
+        q.quantize()
+        return q
+
+    return step
+
+
+def rows_phases(cap, dist):
+    """one extra instrumented sharded quantize(): seconds per phase on this rank"""
+    step = make_sharded_quantize(cap, dist)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    q = step(timing=True)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    st = {k: round(v, 5) for k, v in q.ganq_stats.items() if isinstance(v, float) and k.endswith("_s") and k != "enqueue_s"}
+    st["prologue_epilogue_s"] = round(total - sum(st.values()), 5)
+    st["total_s"] = round(total, 5)
+    return st
+
+
+def opt125m_report(args, cap_unused=None):
+    """BASELINE.json's target is written on opt-125m: whole-model quantization of that ARCHITECTURE (random weights -- no
+    checkpoint is reachable), 72 linears, 128 x 2048 synthetic tokens, K = 10, forward passes included, as columns/s; beside
+    it the C oracle's loop on the three module shapes (one of K iterations on all rows, scaled), i.e. what the CPU needs for
+    the loops alone -- its Hessians, k-means and forward passes are not even counted."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import numpy as np
+    import quantize_model_bench as qmb
+
+    from oracle import c_oracle
+
+    qmb.run("opt-125m", nsamples=16, seqlen=512, batch=8, iters=2, layers=1)  # warm-up: workspaces, library handles
+    log("[bench] opt125m: warm-up done")
+    rep = qmb.run("opt-125m", nsamples=args.nseq, seqlen=args.seqlen, batch=8, bits=args.bits, iters=args.iters)
+    threads, _ = host_cores()
+    c_oracle.set_num_threads(threads)
+    rng = np.random.default_rng(0)
+    cpu_loop_s, per_shape = 0.0, {}
+    for shape, count in rep["module_shapes"].items():
+        m, n = (int(v) for v in shape.split("x"))
+        W = (0.02 * rng.standard_normal((m, n))).astype(np.float32)
+        X = (rng.standard_normal((2 * n, n)) * (0.1 + rng.random(n))).astype(np.float32)
+        H = (X.T @ X / n).astype(np.float64)
+        H += 0.01 * np.mean(np.diag(H)) * np.eye(n)
+        L = np.linalg.cholesky(H + np.diag(np.clip(np.abs(H).sum(1) - 2 * np.diag(H), 1e-8, None))).astype(np.float32)
+        T0 = np.quantile(W, (np.arange(2 ** args.bits) + 0.5) / 2 ** args.bits, axis=1).T.astype(np.float32).copy()
+        t0 = time.perf_counter()
+        c_oracle.run_layer(W, H.astype(np.float32), L, T0, 1)
+        dt = time.perf_counter() - t0
+        per_shape[shape] = {"modules": count, "cpu_one_iteration_s": round(dt, 4)}
+        log(f"[bench] opt125m: C oracle {shape}: {dt:.3f} s per iteration")
+        cpu_loop_s += dt * args.iters * count
+    rep["cpu_loops_only"] = {"kind": "port", "cores": threads, "seconds": round(cpu_loop_s, 2),
+                             "columns_per_s": round(rep["weight_columns"] / cpu_loop_s, 2), "per_shape": per_shape,
+                             "sample": "oracle/ganq_oracle.c, one of K iterations on all rows of each module shape, scaled by K and the "
+                                       "module count; Hessian, k-means and forward passes NOT included on the CPU side"}
+    rep["speedup_whole_gpu_run_vs_cpu_loops_only"] = round(rep["columns_per_s_whole_run"] / rep["cpu_loops_only"]["columns_per_s"], 1)
+    rep["target"] = ">= 50x the reference CPU columns/s on opt-125m 4-bit (BASELINE.json)"
+    return rep
+
+
+def ppl_report(args):
+    """Wiki2 PPL of opt-125m fp16 / GANQ 4-bit (README.md:21-27 of the reference) when the files are on this box"""
+    model = args.model_path or os.environ.get("GANQ_MODEL_PATH")
+    wiki = args.wikitext_path or os.environ.get("GANQ_WIKITEXT_PATH")
+    c4 = args.c4_path or os.environ.get("GANQ_C4_PATH")
+    if not (model and os.path.exists(model) and wiki and os.path.exists(wiki)):
+        return "unmeasured: no checkpoint / dataset on this box (pass --model-path --wikitext-path [--c4-path] or set " \
+               "GANQ_MODEL_PATH / GANQ_WIKITEXT_PATH / GANQ_C4_PATH; reference: opt-125m fp16 27.65, GANQ 4-bit 28.45)"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import eval_ppl
+
+    calib = "c4" if (c4 and os.path.exists(c4)) else "wikitext2"
+    out = eval_ppl.evaluate(model, wiki, c4, calib=calib, nsamples=32, seqlen=2048, bits=args.bits, iters=args.iters)
+    out.pop("modules", None)
+    return out
 
 
 class _SameSeed:
@@ -230,6 +393,10 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lut", action="store_true", help="skip the lut_forward object")
+    ap.add_argument("--no-opt125m", action="store_true", help="skip the opt125m object (whole-model run on the opt-125m architecture)")
+    ap.add_argument("--model-path", default=None, help="local HF model directory: adds measured Wiki2 PPL (fp16 / GANQ) to the line")
+    ap.add_argument("--wikitext-path", default=None)
+    ap.add_argument("--c4-path", default=None)
     ap.add_argument("--mode", choices=["layers", "rows"], default="layers",
                     help="layers: one layer per GPU (weak scaling, the default); rows: one layer, rows split over the GPUs (strong)")
     args = ap.parse_args()
@@ -254,12 +421,16 @@ def main():
     ws = _lib.run_layer_workspace(args.m, args.n, V, dev)
 
     if args.mode == "rows":
+        sharded_step = make_sharded_quantize(cap, dist)
+
         def step():
-            return gdist.run_layer_row_sharded(cap["W"], cap["H"], cap["L"], cap["T0"], args.iters, alias_q=True, dist=dist)
+            q = sharded_step()
+            return None, None, q.ganq_stats["dists"], q.ganq_stats["best_k"]
     else:
         def step():
             return _lib.run_layer(cap["W"], cap["H"], cap["L"], cap["T0"], args.iters, alias_q=True, workspace=ws)
 
+    log(f"[bench] workload ready: {setup}")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -271,6 +442,8 @@ def main():
     prof_all = _lib.profile_report()
     _lib.profile_enable(False)
     dom_name = max(prof_all.items(), key=lambda kv: kv[1][0])[0]
+    if args.mode == "rows" and "solve_s_kernel" in prof_all:
+        dom_name = "solve_s_kernel"  # the roofline object stays on the loop's dominant kernel (k-means is outside t_loop)
     torch.cuda.synchronize()
     if dist.world > 1:
         td.barrier()
@@ -283,6 +456,7 @@ def main():
     if dist.world > 1:
         td.barrier()
     elapsed = time.perf_counter() - t0
+    log(f"[bench] timed region: {args.steps} steps in {elapsed:.4f} s")
     prof = _lib.profile_report()
     _lib.profile_enable(False)
     if dist.world > 1:
@@ -291,6 +465,31 @@ def main():
             t = t.to(dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t)
+
+    # strong-scaling figure: the SAME layer (rank 0's) quantized by all ranks together -- data-parallel statistics are
+    # already reduced in rows mode; in layers mode rank 0's weight and Hessian are broadcast first
+    row_sharded = phases = None
+    if args.mode == "rows":
+        phases = rows_phases(cap, dist)
+    elif dist.world > 1:
+        gdist.broadcast_tensor(cap["lin"].weight.data, 0)
+        gdist.broadcast_tensor(cap["H_raw"], 0)
+        sharded_step = make_sharded_quantize(cap, dist)
+        sharded_step()
+        phases = rows_phases(cap, dist)
+        torch.cuda.synchronize()
+        td.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sharded_step()
+        torch.cuda.synchronize()
+        td.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if td.get_backend() != "gloo" else "cpu")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        row_sharded = {"what": "ONE 4096x4096 layer, complete quantize() on the reduced Hessian (prologue replicated; k-means + fused "
+                               "loop on each rank's row slice; exchange of row losses / chosen rows), rows split over the GPUs: strong scaling",
+                       "columns_per_s": round(args.steps * args.n / float(t), 2), "ms_per_layer": round(float(t) / args.steps * 1e3, 3),
+                       "single_gpu_full_quantize_warm_ms": round(setup["full_quantize_warm_s"] * 1e3, 3), "phases_rank0_s": phases}
 
     exec_rows, exec_frac = None, 1.0
     if dist.rank == 0 and args.mode == "layers":
@@ -331,11 +530,18 @@ def main():
         # (profiles/<PMC_FILE>, tools/pmc_collect.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
         roof["traffic"] = None
         try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_parse import csrc_digest
+
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            for k, v in pmc.items():
-                if k.split("<")[0] == dom_name and (m, n) == (4096, 4096):
-                    roof["traffic"] = int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
-        except (OSError, ValueError, KeyError):
+            if pmc.get("_csrc_sha256") != csrc_digest(ROOT):
+                roof["traffic_note"] = f"profiles/{PMC_FILE} was collected on other kernel sources than the ones running: not reported"
+            else:
+                for k, v in pmc.items():
+                    if k.split("<")[0] == dom_name and (m, n) == (4096, 4096):
+                        roof["traffic"] = int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
+                        roof["traffic_source"] = f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 for gfx950)"
+        except (OSError, ValueError, KeyError, AttributeError):
             pass
         # whole-path HBM view: algorithmic bytes of the loop per layer / loop time
         b_loop = K * (15.0 * m * n + 10.0 * n * n + 8.0 * m * V)
@@ -362,13 +568,25 @@ def main():
             "parity": "this exact workload, K = 10, is checked against the CPU oracle by tests/test_hip_configs.py::"
                       "test_bench_workload_k10_vs_oracle (indices bit-exact, codebooks <= 1e-5, row losses <= 1e-6)",
         }
+        if phases is not None and args.mode == "rows":
+            result["setup"]["rows_phases"] = phases
+        if row_sharded is not None:
+            result["row_sharded"] = row_sharded
         if dist.world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cap, args)
             result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
         if dist.world == 1 and not args.no_lut:
-            del cap, ws  # free the layer before the rings of weights are allocated
+            cap = ws = None  # free the layer before the rings of weights are allocated
             torch.cuda.empty_cache()
+            log("[bench] lut_forward ...")
             result["lut_forward"] = lut_forward_report()
+        if dist.world == 1 and not args.no_opt125m:
+            log("[bench] opt125m (whole-model run on the architecture + C oracle loops) ...")
+            cap = ws = None
+            torch.cuda.empty_cache()
+            result["opt125m"] = opt125m_report(args)
+        if dist.world == 1:
+            result["ppl"] = ppl_report(args)
         print(json.dumps(result), flush=True)
     if dist.world > 1:
         td.barrier()

@@ -32,6 +32,45 @@ def need(path, what):
         raise SystemExit(2)
 
 
+def evaluate(model_path, wikitext_path, c4_path=None, calib="c4", nsamples=32, seqlen=2048, eval_seqlen=2048, bits=4, iters=10,
+             fmt="ganq_lut", outlier_ratio=0.0, skip_fp16=False, save=None, looper_options=None):
+    """fp16 PPL, quantization with the example's configuration, quantized PPL -> dict (see module docstring)"""
+    import torch
+    import transformers
+
+    from ganq_amd.models import (as_batches, get_c4, get_wikitext2, gptq_style_ppl, quantize_model, save_quantized,
+                                 wikitext2_test_ids)
+    from ganq_amd.quantization import QuantizeConfig
+
+    tok = transformers.AutoTokenizer.from_pretrained(model_path, use_fast=True, local_files_only=True)
+    model = transformers.AutoModelForCausalLM.from_pretrained(model_path, torch_dtype=torch.float16,
+                                                              local_files_only=True).cuda().eval()
+    test_ids = wikitext2_test_ids(tok, wikitext_path)
+    out = {"model": model_path, "bits": bits, "ganq_iterations": iters, "calib": calib,
+           "nsamples": nsamples, "seqlen": seqlen, "eval_tokens": int(test_ids.numel())}
+    if not skip_fp16:
+        out["ppl_fp16"] = gptq_style_ppl(model, test_ids, seqlen=eval_seqlen)
+    if calib == "c4":
+        samples = get_c4(tok, nsamples, seqlen, c4_path)
+    else:
+        samples = get_wikitext2(tok, nsamples, seqlen, wikitext_path)
+    qcfg = QuantizeConfig(bits=bits, quant_method="ganq", format=fmt, ganq_iterations=iters, act_sort="asc",
+                          l_damp_style="ganq", dead="mean", ganq_outlier_ratio=outlier_ratio)
+    t0 = time.time()
+    proc = quantize_model(model, as_batches(samples), qcfg, **(looper_options or {}))
+    torch.cuda.synchronize()
+    out["quantize_s"] = round(time.time() - t0, 2)
+    out["ppl_ganq"] = gptq_style_ppl(model, test_ids, seqlen=eval_seqlen)
+    if "ppl_fp16" in out:
+        out["ppl_delta"] = out["ppl_ganq"] - out["ppl_fp16"]
+    out["reference_readme"] = {"opt-125m fp16": 27.65, "opt-125m GANQ 4-bit (CPU path)": 28.45, "window": 0.05}
+    out["modules"] = proc.log
+    if save:
+        save_quantized(model, save, qcfg)
+        out["saved"] = save
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--model-path", required=True)
@@ -55,41 +94,12 @@ def main():
         need(args.c4_path, "c4 shard (en/c4-train.00000-of-01024.json.gz)")
 
     import torch
-    import transformers
-
-    from ganq_amd.models import (as_batches, get_c4, get_wikitext2, gptq_style_ppl, quantize_model, save_quantized,
-                                 wikitext2_test_ids)
-    from ganq_amd.quantization import QuantizeConfig
 
     if not torch.cuda.is_available():
         print("eval_ppl: needs the MI355X (the HIP path has no CPU fallback)", file=sys.stderr)
         raise SystemExit(2)
-    tok = transformers.AutoTokenizer.from_pretrained(args.model_path, use_fast=True, local_files_only=True)
-    model = transformers.AutoModelForCausalLM.from_pretrained(args.model_path, torch_dtype=torch.float16,
-                                                              local_files_only=True).cuda().eval()
-    test_ids = wikitext2_test_ids(tok, args.wikitext_path)
-    out = {"model": args.model_path, "bits": args.bits, "ganq_iterations": args.iters, "calib": args.calib,
-           "nsamples": args.nsamples, "seqlen": args.seqlen, "eval_tokens": int(test_ids.numel())}
-    if not args.skip_fp16:
-        out["ppl_fp16"] = gptq_style_ppl(model, test_ids, seqlen=args.eval_seqlen)
-    if args.calib == "c4":
-        samples = get_c4(tok, args.nsamples, args.seqlen, args.c4_path)
-    else:
-        samples = get_wikitext2(tok, args.nsamples, args.seqlen, args.wikitext_path)
-    qcfg = QuantizeConfig(bits=args.bits, quant_method="ganq", format=args.format, ganq_iterations=args.iters, act_sort="asc",
-                          l_damp_style="ganq", dead="mean", ganq_outlier_ratio=args.outlier_ratio)
-    t0 = time.time()
-    proc = quantize_model(model, as_batches(samples), qcfg)
-    torch.cuda.synchronize()
-    out["quantize_s"] = round(time.time() - t0, 2)
-    out["ppl_ganq"] = gptq_style_ppl(model, test_ids, seqlen=args.eval_seqlen)
-    if "ppl_fp16" in out:
-        out["ppl_delta"] = out["ppl_ganq"] - out["ppl_fp16"]
-    out["reference_readme"] = {"opt-125m fp16": 27.65, "opt-125m GANQ 4-bit (CPU path)": 28.45, "window": 0.05}
-    out["modules"] = proc.log
-    if args.save:
-        save_quantized(model, args.save, qcfg)
-        out["saved"] = args.save
+    out = evaluate(args.model_path, args.wikitext_path, args.c4_path, args.calib, args.nsamples, args.seqlen, args.eval_seqlen,
+                   args.bits, args.iters, args.format, args.outlier_ratio, args.skip_fp16, args.save)
     print(json.dumps(out))
 
 

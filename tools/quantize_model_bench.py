@@ -26,6 +26,48 @@ ARCHS = {
 }
 
 
+def run(arch="opt-125m", nsamples=128, seqlen=2048, batch=8, bits=4, iters=10, layers=0, looper_options=None):
+    import transformers
+
+    from ganq_amd.models import gptq_style_ppl, quantize_model
+    from ganq_amd.quantization import QuantizeConfig
+
+    kind, kw = ARCHS[arch]
+    if layers:
+        kw = dict(kw, num_hidden_layers=layers)
+    torch.manual_seed(0)
+    cfg = (transformers.OPTConfig if kind == "opt" else transformers.LlamaConfig)(**kw)
+    model = (transformers.OPTForCausalLM if kind == "opt" else transformers.LlamaForCausalLM)(cfg).half().cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    calib = [torch.randint(0, cfg.vocab_size, (batch, seqlen), generator=g) for _ in range(nsamples // batch)]
+    test_ids = torch.randint(0, cfg.vocab_size, (1, seqlen * 4), generator=g)
+    ppl_fp = gptq_style_ppl(model, test_ids, seqlen)
+    qcfg = QuantizeConfig(bits=bits, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=iters,
+                          damp_percent=0.01, desc_act=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    proc = quantize_model(model, calib, qcfg, **(looper_options or {}))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ppl_q = gptq_style_ppl(model, test_ids, seqlen)
+    quant_s = sum(float(r["time"]) for r in proc.log)
+    cols = sum(m.in_features for m in model.modules() if type(m).__name__ == "GanqHipQuantLinear")
+    shapes = {}
+    for m in model.modules():
+        if type(m).__name__ == "GanqHipQuantLinear":
+            shapes[(m.out_features, m.in_features)] = shapes.get((m.out_features, m.in_features), 0) + 1
+    by_name = {}
+    for r in proc.log:
+        by_name[r["module"]] = by_name.get(r["module"], 0.0) + float(r["time"])
+    return {"arch": arch, "layers": cfg.num_hidden_layers, "modules": len(proc.log), "bits": bits,
+            "ganq_iterations": iters, "calibration": f"{nsamples}x{seqlen} synthetic tokens",
+            "total_s": round(dt, 3), "sum_module_quantize_s": round(quant_s, 3),
+            "quantize_s_by_module": {k: round(v, 3) for k, v in by_name.items()}, "weight_columns": cols,
+            "columns_per_s_whole_run": round(cols / dt, 1),
+            "module_shapes": {f"{m}x{n}": c for (m, n), c in sorted(shapes.items())},
+            "ppl_random_init_fp16": round(ppl_fp, 2), "ppl_random_init_ganq": round(ppl_q, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--arch", default="opt-125m", choices=sorted(ARCHS))
@@ -36,39 +78,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--layers", type=int, default=0, help="truncate the model to this many layers (0 = all)")
     a = ap.parse_args()
-    import transformers
-
-    from ganq_amd.models import gptq_style_ppl, quantize_model
-    from ganq_amd.quantization import QuantizeConfig
-
-    kind, kw = ARCHS[a.arch]
-    if a.layers:
-        kw = dict(kw, num_hidden_layers=a.layers)
-    torch.manual_seed(0)
-    cfg = (transformers.OPTConfig if kind == "opt" else transformers.LlamaConfig)(**kw)
-    model = (transformers.OPTForCausalLM if kind == "opt" else transformers.LlamaForCausalLM)(cfg).half().cuda().eval()
-    g = torch.Generator().manual_seed(1)
-    calib = [torch.randint(0, cfg.vocab_size, (a.batch, a.seqlen), generator=g) for _ in range(a.nsamples // a.batch)]
-    test_ids = torch.randint(0, cfg.vocab_size, (1, a.seqlen * 4), generator=g)
-    ppl_fp = gptq_style_ppl(model, test_ids, a.seqlen)
-    qcfg = QuantizeConfig(bits=a.bits, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=a.iters,
-                          damp_percent=0.01, desc_act=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    proc = quantize_model(model, calib, qcfg)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ppl_q = gptq_style_ppl(model, test_ids, a.seqlen)
-    quant_s = sum(float(r["time"]) for r in proc.log)
-    cols = sum(m.in_features for m in model.modules() if type(m).__name__ == "GanqHipQuantLinear")
-    by_name = {}
-    for r in proc.log:
-        by_name[r["module"]] = by_name.get(r["module"], 0.0) + float(r["time"])
-    print(json.dumps({"arch": a.arch, "layers": cfg.num_hidden_layers, "modules": len(proc.log), "bits": a.bits,
-                      "ganq_iterations": a.iters, "calibration": f"{a.nsamples}x{a.seqlen} synthetic tokens",
-                      "total_s": round(dt, 3), "sum_module_quantize_s": round(quant_s, 3),
-                      "quantize_s_by_module": {k: round(v, 3) for k, v in by_name.items()}, "weight_columns": cols, "columns_per_s_whole_run": round(cols / dt, 1),
-                      "ppl_random_init_fp16": round(ppl_fp, 2), "ppl_random_init_ganq": round(ppl_q, 2)}))
+    print(json.dumps(run(a.arch, a.nsamples, a.seqlen, a.batch, a.bits, a.iters, a.layers)))
 
 
 if __name__ == "__main__":
