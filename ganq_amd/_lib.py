@@ -539,7 +539,8 @@ def lut_linear_outliers(x, qweight, lut, bias, bits: int, rowptr, cols, vals):
 
 
 def lut_linear(x, qweight, lut, bias, bits: int, addend=None):
-    """x [M,n] (M <= 64) fp16/bf16, qweight int32 [n*bits/32, m], lut [m,V], bias [m] or None -> y [M,m].
+    """x [M,n] fp16/bf16 (any M: decode kernels up to 64 rows, the fused LUT-dequant GEMM above), qweight int32 [n*bits/32, m],
+    lut [m,V], bias [m] or None -> y [M,m].
     addend: optional fp32 [M,m] added before the rounding to x's dtype (the sparse-outlier product)."""
     code = _act_dtype(x, "x")
     if lut.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype):

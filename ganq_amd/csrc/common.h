@@ -62,6 +62,7 @@ enum Opt : int {
     OPT_H_EXT,
     OPT_SOLVE_VARIANT,
     OPT_LUT_NT,
+    OPT_LUT_GEMM_RM,
     OPT_COUNT
 };
 long long opt_get(int id);

@@ -1,0 +1,345 @@
+// LUT-dequant GEMM for M > 64 rows of x (prefill, perplexity evaluation at seqlen 2048):
+//   y[M,m] = x[M,n] @ dequant(qweight, lut)^T (+ addend) (+ bias)        fake.py:88-89 with the weight never materialised
+//
+// One workgroup = a BM x BN tile of y (BM = 128 or 256 rows of x, BN = 128 output features), 4 waves as 2 x 2, every wave a
+// (BM / 2) x 64 sub-tile = RM x 2 v_mfma_f32_32x32x16_{f16,bf16} tiles, fp32 accumulation over all of in_features (no split-K: one rounding).
+//   A operand (activations): a BM x 128 slab of x per stage goes through LDS (row pitch 256 + 16 B: the 16-byte fragment
+//     reads of 16 consecutive rows fall on 64 distinct banks); the global loads of a stage -- slab and weight words -- are
+//     issued a whole stage (16 or 32 matrix instructions per wave) before they are needed.
+//   B operand (weights): decoded straight into the matrix-core operand, never written anywhere.  In the 32x32x16 layout lane
+//     l holds output feature l % 32 and the 8 consecutive in_features 8 * (l / 32) .. of a 16-column step -- exactly 8 * BITS
+//     consecutive bits of that feature's GPTQ bit stream: one word load (two for 3-bit), 8 codebook lookups in LDS
+//     (tbl[tile][entry][lane]: one dword slot per lane and entry, conflict-free; v_perm builds the addresses for 4-bit),
+//     4 packs.  The packed weight is read once per BM rows: 1/4 of the fp16 bytes at 4 bits.
+// The workgroups of one launch are dealt to the 8 XCDs round-robin by the hardware; the tile index is remapped so that the
+// workgroups behind one L2 walk the SAME row block of x over consecutive feature blocks (x is the large operand).
+#include "common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace ganq {
+
+typedef _Float16 g_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float g_f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t g_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t g_lds_pair(uint32_t addr_lo, uint32_t addr_hi) {
+    typedef const uint32_t __attribute__((address_space(3))) * lds_u32;
+    return *reinterpret_cast<lds_u32>(addr_lo) | (*reinterpret_cast<lds_u32>(addr_hi) << 16);
+}
+
+constexpr int GBN = 128;      // output features per workgroup
+constexpr int GBM = 256;      // rows of x per workgroup: 4 waves x 64 rows
+constexpr int GST = 2;        // groups of 32 in_features per stage
+constexpr int GPITCH = 64 * GST + 16;  // bytes per LDS row (activations and decoded weights alike): + 16 B so that the 16-byte
+                                       // fragment reads of 16 consecutive rows hit 64 distinct banks
+
+// One workgroup = a 256 x 128 tile of y.  Wave w owns rows 64 w .. 64 w + 63 and ALL 128 features: 2 x 4 tiles of
+// v_mfma_f32_32x32x16, every activation fragment feeds four matrix instructions, every weight fragment two.
+// The weights of a stage are decoded ONCE per workgroup into an fp16 / bf16 tile in LDS (thread = one output feature and two
+// of the four 8-column octets of every 32-column group: one word load, 8 conflict-free codebook lookups, one 16-byte LDS
+// store per octet) -- a quarter of the lookups a per-wave decode into registers costs, which had bound the first version of this
+// kernel (371 vector + 144 LDS instructions per 32 matrix instructions).
+// SPLIT: blockIdx.y = ks takes the stages [ks * st_per, (ks + 1) * st_per) of in_features and writes its fp32 partial tile;
+// lut_gemm_reduce_kernel, the next launch on the stream, sums the splits in ks order (deterministic), adds addend / bias and
+// rounds once.  Serves 64 < M <= ~1024, where whole-K tiles would leave CUs idle.
+template <int BITS, bool BF16, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void lut_gemm_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                        const uint16_t* __restrict__ lut, const uint16_t* __restrict__ bias,
+                                                        const float* __restrict__ addend, int M, int m, int n, int tiles_m,
+                                                        int tiles_n, uint16_t* __restrict__ y, int st_per,
+                                                        float* __restrict__ partial) {
+    constexpr int V = 1 << BITS;
+    constexpr bool STRADDLE = (8 * BITS) % 16 != 0;  // 3-bit: an octet's 24 bits can span two words
+    constexpr int TPR = 4 * GST;                     // threads per slab row (16 B each)
+    constexpr int RPP = 256 / TPR;                   // rows per pass of the 256 threads
+    constexpr int NLD = GBM / RPP;                   // 16-byte activation loads per thread and stage
+    constexpr int NIT = 2 * GST;                     // (group, octet) items a thread decodes per stage
+    __shared__ __attribute__((aligned(4096))) uint32_t tbl[2][V][64];  // [feature half][entry][lane]: waves w and w + 2 share
+    __shared__ __attribute__((aligned(16))) unsigned char As[GBM * GPITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[GBN * GPITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hf = lane >> 5;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD whole row blocks of x
+    int bid = blockIdx.x;
+    {
+        const int total = tiles_m * tiles_n;
+        const int per = total >> 3;
+        if ((total & 7) == 0) bid = (bid & 7) * per + (bid >> 3);  // (otherwise the plain order: the remap would leave holes)
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int r0 = tm * GBM, o0 = tn * GBN;
+    const int nkb = n >> 5, nst_all = (nkb + GST - 1) / GST;
+    const int st_begin = SPLIT ? (int)blockIdx.y * st_per : 0;
+    const int nst = SPLIT ? min(nst_all, st_begin + st_per) : nst_all;  // this workgroup's stages: [st_begin, nst)
+
+    // ---- decode role: this thread's feature and octets
+    const int dfeat = tid & 127, dq0 = tid >> 7;  // octets dq0 and dq0 + 2 of every group
+    const int dcol = min(o0 + dfeat, m - 1);
+    if (wv < 2) {  // the codebook of feature o0 + 64 * wv + lane, one dword slot per entry and lane
+        const uint32_t* lp = reinterpret_cast<const uint32_t*>(lut + (int64_t)dcol * V);
+        uint32_t h[V / 2];
+#pragma unroll
+        for (int e = 0; e < V / 2; ++e) h[e] = lp[e];
+#pragma unroll
+        for (int e = 0; e < V / 2; ++e) {
+            tbl[wv][2 * e][lane] = h[e] & 0xffffu;
+            tbl[wv][2 * e + 1][lane] = h[e] >> 16;
+        }
+    }
+    int wi[2], sh[2], wi2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int off = 8 * BITS * (dq0 + 2 * j);  // bit offset of the octet inside the 32-column group
+        wi[j] = off >> 5;
+        sh[j] = off & 31;
+        wi2[j] = STRADDLE ? min(wi[j] + 1, BITS - 1) : wi[j];
+    }
+
+    // ---- global -> register staging of one stage
+    const int achunk = tid % TPR, arow0 = tid / TPR;  // rows arow0 + RPP * i
+    // rows past M are clamped, not zeroed: what they produce lands in accumulator rows that are never stored
+    const uint16_t* xrow[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) xrow[i] = x + (int64_t)min(r0 + arow0 + RPP * i, M - 1) * n;
+    g_u32x4 xa[NLD];
+    uint32_t wl[NIT], wh[NIT];  // item = (group g, octet dq0 + 2 j): index 2 g + j
+    // nothing may touch the loaded registers here: a select right behind the loads makes the compiler wait for them on the
+    // spot (measured: a third of the kernel's time); the columns of a ragged last stage are zeroed where the slab is stored
+    auto gload = [&](int st) {
+        const int col = 32 * GST * st + 8 * achunk;  // first in_feature of this thread's chunk
+        const int colc = col < n ? col : 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) xa[i] = *reinterpret_cast<const g_u32x4*>(xrow[i] + colc);
+#pragma unroll
+        for (int g = 0; g < GST; ++g) {
+            const int kb = min(GST * st + g, nkb - 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wl[2 * g + j] = qw[(int64_t)(kb * BITS + wi[j]) * m + dcol];
+                if (STRADDLE) wh[2 * g + j] = qw[(int64_t)(kb * BITS + wi2[j]) * m + dcol];
+            }
+        }
+    };
+    const uint32_t tb = (uint32_t)(uintptr_t)(&tbl[0][0][0]) + (uint32_t)(wv & 1) * (V * 256u);
+    const uint32_t lane4 = 4u * lane;
+    auto sstore = [&](int st) {  // registers -> LDS: the activation slab as it is, the weights decoded
+        const bool col_ok = 32 * GST * st + 8 * achunk < n;  // false only in a ragged last stage
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            *reinterpret_cast<g_u32x4*>(As + (arow0 + RPP * i) * GPITCH + 16 * achunk) = col_ok ? xa[i] : g_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int g = 0; g < GST; ++g)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t bits = wl[2 * g + j] >> sh[j];
+                if (STRADDLE) bits = (uint32_t)((((uint64_t)wh[2 * g + j] << 32) | wl[2 * g + j]) >> sh[j]);
+                g_u32x4 b;
+                if (BITS == 4) {
+                    const uint32_t hib = ((tb >> 8) & 0xffu) * 0x01010101u;
+                    const uint32_t lo = (bits & 0x0f0f0f0fu) | hib, hi = ((bits >> 4) & 0x0f0f0f0fu) | hib;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        b[p] = g_lds_pair(__builtin_amdgcn_perm(lo, lane4, 0x0c0c0000u | ((4u + p) << 8)),
+                                          __builtin_amdgcn_perm(hi, lane4, 0x0c0c0000u | ((4u + p) << 8)));
+                } else {
+                    const uint32_t base = tb + lane4;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        b[p] = g_lds_pair((((bits >> (BITS * (2 * p))) & (V - 1)) << 8) + base,
+                                          (((bits >> (BITS * (2 * p + 1))) & (V - 1)) << 8) + base);
+                }
+                *reinterpret_cast<g_u32x4*>(Bs + dfeat * GPITCH + 64 * g + 16 * (dq0 + 2 * j)) = b;
+            }
+    };
+
+    g_f32x16 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+
+    gload(st_begin);
+    __syncthreads();  // codebook table
+    sstore(st_begin);
+    __syncthreads();  // first slab + weight tile
+    if (st_begin + 1 < nst) gload(st_begin + 1);
+    const unsigned char* abase = As + (64 * wv + l31) * GPITCH + 16 * hf;
+    const unsigned char* bbase = Bs + l31 * GPITCH + 16 * hf;
+    for (int st = st_begin; st < nst; ++st) {
+        // ---- 2 * GST sub-steps of 16 in_features; the fragments of sub-step u + 1 are read before the matrix instructions of u
+        g_u32x4 a_cur[2], b_cur[4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) a_cur[r] = *reinterpret_cast<const g_u32x4*>(abase + 32 * r * GPITCH);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b_cur[t] = *reinterpret_cast<const g_u32x4*>(bbase + 32 * t * GPITCH);
+#pragma unroll
+        for (int u = 0; u < 2 * GST; ++u) {
+            g_u32x4 a_nxt[2], b_nxt[4];
+            if (u + 1 < 2 * GST) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) a_nxt[r] = *reinterpret_cast<const g_u32x4*>(abase + 32 * r * GPITCH + 32 * (u + 1));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b_nxt[t] = *reinterpret_cast<const g_u32x4*>(bbase + 32 * t * GPITCH + 32 * (u + 1));
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (BF16)
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8, a_cur[r]),
+                                                                            __builtin_bit_cast(g_bf16x8, b_cur[t]), acc[r][t], 0, 0, 0);
+                    else
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(g_f16x8, a_cur[r]),
+                                                                           __builtin_bit_cast(g_f16x8, b_cur[t]), acc[r][t], 0, 0, 0);
+                }
+            if (u + 1 < 2 * GST) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) a_cur[r] = a_nxt[r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b_cur[t] = b_nxt[t];
+            }
+        }
+        if (st + 1 < nst) {
+            __syncthreads();  // every wave has read this stage's tiles
+            sstore(st + 1);   // the next stage (its loads were issued a stage ago)
+            __syncthreads();
+            if (st + 2 < nst) gload(st + 2);
+        }
+    }
+
+    // C layout of the 32x32 tile: column (feature) = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if constexpr (SPLIT) {  // this split's fp32 partial tile; lut_gemm_reduce_kernel (next launch on the stream) sums the splits
+        const int ks = blockIdx.y;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int o = o0 + 32 * t + l31;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = r0 + 64 * wv + 32 * r + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+                    if (o < m && row < M) partial[((int64_t)ks * M + row) * m + o] = acc[r][t][reg];
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int o = o0 + 32 * t + l31;
+        if (o >= m) continue;
+        float bv = 0.f;
+        if (bias) bv = BF16 ? __builtin_bit_cast(float, (uint32_t)bias[o] << 16) : (float)__builtin_bit_cast(_Float16, bias[o]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[r][t][reg] += bv;
+    }
+    auto emit = [&](auto with_addend) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int o = o0 + 32 * t + l31;
+            if (o >= m) continue;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = r0 + 64 * wv + 32 * r + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+                    if (row >= M) continue;
+                    float v = acc[r][t][reg];
+                    if (decltype(with_addend)::value) v += addend[(int64_t)row * m + o];
+                    y[(int64_t)row * m + o] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v) : __builtin_bit_cast(uint16_t, (_Float16)v);
+                }
+        }
+    };
+    if (addend) emit(std::true_type{});
+    else emit(std::false_type{});
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void lut_gemm_reduce_kernel(const float* __restrict__ partial, const uint16_t* __restrict__ bias,
+                                                              const float* __restrict__ addend, int64_t total, int m, int KS,
+                                                              uint16_t* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // element of y, row-major
+    if (i >= total) return;
+    float v = 0.f;
+    for (int ks = 0; ks < KS; ++ks) v += partial[(int64_t)ks * total + i];  // split order
+    if (addend) v += addend[i];
+    if (bias) {
+        const uint16_t b = bias[i % m];
+        v += BF16 ? __builtin_bit_cast(float, (uint32_t)b << 16) : (float)__builtin_bit_cast(_Float16, b);
+    }
+    y[i] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v) : __builtin_bit_cast(uint16_t, (_Float16)v);
+}
+
+struct GemmPlan {
+    int tiles_m, tiles_n, KS, st_per;
+    size_t partial_bytes;
+};
+GemmPlan lut_gemm_plan(int64_t M, int64_t m, int64_t n) {
+    GemmPlan p;
+    p.tiles_m = (int)((M + GBM - 1) / GBM);
+    p.tiles_n = (int)((m + GBN - 1) / GBN);
+    const int nst = (int)(((n >> 5) + GST - 1) / GST);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    // split in_features while the launch has fewer workgroups than CUs, every split keeping at least 8 stages (512 columns)
+    const int force = (int)opt_get(OPT_LUT_GEMM_RM);  // developer switch: forced split factor
+    int ks = 1;
+    while (ks < 8 && tiles * ks < 256 && nst / (2 * ks) >= 8) ks *= 2;
+    if (force > 0) ks = std::min(force, nst);
+    p.st_per = (nst + ks - 1) / ks;
+    p.KS = (nst + p.st_per - 1) / p.st_per;
+    p.partial_bytes = p.KS > 1 ? align_up((size_t)p.KS * (size_t)M * (size_t)m * sizeof(float), 256) : 0;
+    return p;
+}
+
+template <int BITS>
+static int launch_gemm_bits(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, int dtype, int M,
+                            int m, int n, void* y, const GemmPlan& p, float* partial, hipStream_t stream) {
+    const uint16_t* xp = static_cast<const uint16_t*>(x);
+    const uint16_t* lp = static_cast<const uint16_t*>(lut);
+    const uint16_t* bp = static_cast<const uint16_t*>(bias);
+    uint16_t* yp = static_cast<uint16_t*>(y);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.KS);
+#define GANQ_GEMM_LAUNCH(BF, SP)                                                                                                 \
+    hipLaunchKernelGGL((lut_gemm_kernel<BITS, BF, SP>), grid, dim3(256), 0, stream, xp, qw, lp, bp, addend, M, m, n, p.tiles_m,  \
+                       p.tiles_n, yp, p.st_per, partial)
+    if (p.KS > 1) {
+        const int64_t total = (int64_t)M * m;
+        const dim3 rgrid((unsigned)((total + 255) / 256));
+        if (dtype == 1) {
+            GANQ_GEMM_LAUNCH(true, true);
+            hipLaunchKernelGGL(lut_gemm_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, bp, addend, total, m, p.KS, yp);
+        } else {
+            GANQ_GEMM_LAUNCH(false, true);
+            hipLaunchKernelGGL(lut_gemm_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, bp, addend, total, m, p.KS, yp);
+        }
+    } else {
+        if (dtype == 1) GANQ_GEMM_LAUNCH(true, false);
+        else GANQ_GEMM_LAUNCH(false, false);
+    }
+#undef GANQ_GEMM_LAUNCH
+    GANQ_LAUNCH_CHECK();
+    return 0;
+}
+
+// called by lut_linear_fwd (lut_linear.hip) for M > 64; arguments are already validated there
+size_t lut_gemm_workspace_bytes(int64_t M, int64_t m, int64_t n) { return lut_gemm_plan(M, m, n).partial_bytes; }
+
+int lut_gemm(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, int dtype, int64_t M,
+             int64_t m, int64_t n, int bits, void* y, float* partial, size_t partial_bytes, hipStream_t stream) {
+    if (M > INT32_MAX / 2) return fail(-1, "ganq_lut_linear_fwd: M too large");
+    const GemmPlan p = lut_gemm_plan(M, m, n);
+    if (p.KS > 1 && (!partial || partial_bytes < p.partial_bytes))
+        return fail(-4, "ganq_lut_linear_fwd: workspace %zu B < required %zu B of partial tiles", partial_bytes, p.partial_bytes);
+    if (bits == 2) return launch_gemm_bits<2>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, y, p, partial, stream);
+    if (bits == 3) return launch_gemm_bits<3>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, y, p, partial, stream);
+    return launch_gemm_bits<4>(x, qw, lut, bias, addend, dtype, (int)M, (int)m, (int)n, y, p, partial, stream);
+}
+
+}  // namespace ganq

@@ -9,8 +9,8 @@
 // ganq_lut_linear_fwd (M <= 64 rows, decode / small batches): weights are decoded straight into the B operand of
 //   v_mfma_f32_16x16x32_{f16,bf16} (codebook lookups in LDS), activations are the A operand, fp32 accumulation;
 //   the in_features range is split over workgroups and waves (deterministic two-stage reduction).
-// ganq_lut_dequant: materialises W_q [m,n] in the activation dtype for large-M products (prefill), which the
-//   host side hands to a library GEMM.
+//   M > 64: lut_gemm.hip (fused LUT-dequant GEMM).
+// ganq_lut_dequant: materialises W_q [m,n] in the activation dtype (dequantize_weight(), tests, A/B runs against a library GEMM).
 #include "common.h"
 
 namespace ganq {
@@ -672,12 +672,18 @@ static LutPlan lut_plan(int64_t M, int64_t m, int64_t n, int bits) {
     return p;
 }
 
+// lut_gemm.hip: the fused LUT-dequant GEMM that serves M > LUT_MAX_M (prefill)
+int lut_gemm(const void* x, const uint32_t* qw, const void* lut, const void* bias, const float* addend, int dtype, int64_t M,
+             int64_t m, int64_t n, int bits, void* y, float* partial, size_t partial_bytes, hipStream_t stream);
+size_t lut_gemm_workspace_bytes(int64_t M, int64_t m, int64_t n);
+
 }  // namespace ganq
 
 using namespace ganq;
 
 extern "C" size_t ganq_lut_linear_workspace_bytes(int64_t M, int64_t m, int64_t n, int bits) {
     if (M <= 0 || m <= 0 || n < 32) return 0;
+    if (M > LUT_MAX_M) return LUT_COUNTER_BYTES + lut_gemm_workspace_bytes(M, m, n);  // counters + split-K partial tiles
     return lut_plan(M, m, n, bits).bytes;
 }
 
@@ -774,11 +780,21 @@ static int lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut
     if (M == 0 || m == 0) return 0;
     int rc = check_lut_args("ganq_lut_linear_fwd", dtype, m, n, bits);
     if (rc) return rc;
-    if (M > LUT_MAX_M)
-        return fail(-2, "ganq_lut_linear_fwd: M=%lld > %d; use ganq_lut_dequant + a GEMM for large batches", (long long)M, LUT_MAX_M);
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(-2, "ganq_lut_linear_fwd: x must be 16-byte aligned");
     if ((reinterpret_cast<uintptr_t>(lut) & 3) != 0) return fail(-2, "ganq_lut_linear_fwd: lut must be 4-byte aligned");
     if (!x || !qweight || !lut || !y) return fail(-3, "ganq_lut_linear_fwd: null pointer");
+    if (M > LUT_MAX_M) {  // prefill: the fused LUT-dequant GEMM (lut_gemm.hip); the weight is never materialised
+        if (csr.rowptr)
+            return fail(-2, "ganq_lut_linear_fwd: outliers fused into the launch serve M <= %d; for larger M pass their product as "
+                            "the fp32 addend (ganq_outlier_matmul + ganq_lut_linear_fwd_add)", LUT_MAX_M);
+        hipStream_t gstream = static_cast<hipStream_t>(stream_);
+        if (!workspace || workspace_bytes < LUT_COUNTER_BYTES)
+            return fail(-4, "ganq_lut_linear_fwd: workspace %zu B < required %zu B", workspace_bytes, LUT_COUNTER_BYTES);
+        ProfScope gprof(KID_LUT_GEMM, gstream);
+        return lut_gemm(x, reinterpret_cast<const uint32_t*>(qweight), lut, bias, addend, dtype, M, m, n, bits, y,
+                        reinterpret_cast<float*>(static_cast<char*>(workspace) + LUT_COUNTER_BYTES), workspace_bytes - LUT_COUNTER_BYTES,
+                        gstream);
+    }
     const LutPlan p = lut_plan(M, m, n, bits);
     if ((size_t)p.ob * sizeof(int) > LUT_COUNTER_BYTES)
         return fail(-2, "ganq_lut_linear_fwd: out_features=%lld needs more than %zu ticket counters", (long long)m,

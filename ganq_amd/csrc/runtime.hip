@@ -40,6 +40,7 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"GANQ_H_EXT", -1},            // fixed-point H: 1 force / 0 forbid the 16-bit extension word (-1: decided on the device)
     {"GANQ_SOLVE_VARIANT", 0},     // S-solve scheduling variant (developer A/B)
     {"GANQ_LUT_NT", 0},            // LUT decode kernel: force 1 / 2 tiles of 16 features per workgroup (0: by shape)
+    {"GANQ_LUT_GEMM_RM", 0},       // LUT GEMM (M > 64): force this split factor of in_features (0: by shape)
 };
 
 std::atomic<long long> g_opt[OPT_COUNT];

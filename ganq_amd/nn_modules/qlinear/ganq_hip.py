@@ -134,18 +134,13 @@ class GanqHipQuantLinear(BaseQuantLinear):
             bias = None if bias is None else bias.to(x.dtype)
         out_shape = x.shape[:-1] + (self.out_features,)
         x2 = x.reshape(-1, self.in_features)
-        if x2.shape[0] <= GEMV_MAX_ROWS:
-            if self.outliers:  # x @ W_sparse^T in fp32, added inside the LUT kernel before its one rounding
-                vals = self.outlier_vals if self.outlier_vals.dtype == x.dtype else self.outlier_vals.to(x.dtype)
-                y = _lib.lut_linear_outliers(x2, self.qweight, lut, bias, self.bits, self.outlier_rowptr, self.outlier_cols, vals)
-            else:
-                y = _lib.lut_linear(x2, self.qweight, lut, bias, self.bits)
+        # one C-ABI entry for every batch size: the decode kernels up to 64 rows, the fused LUT-dequant GEMM above
+        # (csrc/lut_gemm.hip) -- the dequantised weight is never materialised and no library GEMM is called
+        if self.outliers:  # x @ W_sparse^T in fp32, added inside the LUT kernel before its one rounding
+            vals = self.outlier_vals if self.outlier_vals.dtype == x.dtype else self.outlier_vals.to(x.dtype)
+            y = _lib.lut_linear_outliers(x2, self.qweight, lut, bias, self.bits, self.outlier_rowptr, self.outlier_cols, vals)
         else:
-            # prefill: dequantise with the HIP kernel, then a plain library GEMM
-            Wq = _lib.lut_dequant(self.qweight, lut, self.in_features, self.bits)
-            if self.outliers:
-                Wq = Wq + self._sparse_dense(Wq.dtype)
-            y = torch.nn.functional.linear(x2, Wq, bias)
+            y = _lib.lut_linear(x2, self.qweight, lut, bias, self.bits)
         return y.reshape(out_shape)
 
 

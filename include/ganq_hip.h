@@ -133,8 +133,11 @@ int ganq_select_best(const double* loss_rows_all, int64_t m, int K, double* dist
  * y[M,m] = x[M,n] @ dequant(qweight, lut)^T + bias.   dtype: 0 = fp16, 1 = bf16 (x, lut, bias, y).
  * qweight: indices packed `bits` per index along the in_features dimension in the GPTQ int32
  * layout qweight[n*bits/32, m] (qlinear/__init__.py:508-517); lut [m,V]; bias [m] or NULL.     */
-/* decode / small-batch path, M <= 64 rows, x 16-byte aligned.  One kernel: split-K partial tiles plus one ticket
+/* Any M, x 16-byte aligned.  M <= 64 (decode / small batches): one kernel, split-K partial tiles plus one ticket
  * counter per block of 128 features live in the workspace; the last workgroup of a block reduces and writes y.
+ * M > 64 (prefill, perplexity evaluation): the fused LUT-dequant GEMM (csrc/lut_gemm.hip) -- weights decoded into the
+ * matrix-core operand tile, never materialised; for few row blocks in_features is split over workgroups, the fp32
+ * partial tiles live in the workspace and a second launch sums them in split order (deterministic).
  * The workspace must be zero-filled ONCE after allocation (ganq_lut_linear_workspace_init); every call leaves the
  * counters zero again, so it can be reused by later calls of any shape that fits.  One workspace serves one stream
  * at a time.                                                                                                    */
