@@ -112,11 +112,17 @@ __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, 
                 // buffer loads: the slab's byte offset in an SGPR, this thread's constant offset inside a slab in a VGPR -- no
                 // per-load 64-bit address arithmetic (it was a fifth of a slab step: 610 of 2900 cycles by the stamps); the
                 // resource ends with the last token row, so rows past the end read as zeros by themselves
+                // Token rows past the end exist only in the last slabs (and the look-ahead behind them).  For THOSE the slab
+                // offset travels in the VGPR offset, which the hardware compares with num_records in every addressing mode
+                // (offset >= num_records reads 0, nothing is fetched); whether the SGPR offset takes part in that comparison
+                // differs between descriptions of the gfx9 family, and this kernel does not depend on it.
                 (void)t;
                 (void)f8;
                 const int soff = t0 * n * 2;
-                va = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offA[h], soff, 0));
-                vb = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offB[h], soff, 0));
+                const bool past = t0 + HK > rows;  // uniform
+                const int so = past ? 0 : soff, vo = past ? soff : 0;
+                va = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offA[h] + vo, so, 0));
+                vb = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offB[h] + vo, so, 0));
             } else {
               if (t < rows) {
                 const uint16_t* pa = X + (int64_t)t * n + u0 + f8;
@@ -326,6 +332,7 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
     // The kernel's fast path addresses X through 32-bit buffer offsets: a batch of more than ~2 GB goes in pieces of whole
     // slabs -- the first with the batch's decay, the others adding to it (decay 1) with the same scale; the same sum in the
     // same token order.
+    // (in_features beyond ~6.7 M would make a piece a single slab and every piece a read-modify-write of H; no layer is near)
     const int64_t piece_max = std::max<int64_t>(HK, (((int64_t)1 << 31) / (2 * n) - 4 * HK - 1) / HK * HK);
     const uint16_t* Xp = static_cast<const uint16_t*>(X);
     int64_t done = 0;

@@ -289,6 +289,10 @@ class ModuleLooper:
                         gdist.reduce_group_statistics([self.processor.tasks[n] for n in hooked_names], dist, self.dist_stats)
                 for h in handles:
                     h.remove()
+                for n in hooked_names:  # staged calibration batches -> Hessian kernel, staging buffers freed
+                    end = getattr(self.processor.tasks[n], "end_of_calibration", None)
+                    if end is not None:
+                        end()
                 todo = []
                 for n in mine:
                     if self.processor.is_skipped(named[n]):

@@ -42,8 +42,11 @@ def _read_file(path: str) -> List[str]:
                     out.append(json.loads(line)["text"])
         return out
     if low.endswith(".txt"):
-        with open(path, "rt", encoding="utf-8") as f:
-            return [line.rstrip("\n") for line in f]
+        # one record per line, the trailing newline KEPT (only a CR is dropped): the hub's wikitext-2-raw records end with
+        # "\n" and include the blank-line records, and both the `len(text) >= seqlen` filter and the "\n\n".join(test) token
+        # stream of basic_usage_wikitext2.py:26-30,67-68 see them that way
+        with open(path, "rt", encoding="utf-8", newline="") as f:
+            return [line[:-2] + "\n" if line.endswith("\r\n") else line for line in f]
     raise ValueError(f"unsupported dataset file `{path}` (want .parquet, .json[l][.gz] or .txt)")
 
 

@@ -81,22 +81,37 @@ def create_quant_layer(linear_cls: Type[BaseQuantLinear], bits: int, desc_act: b
                        pack_dtype: torch.dtype, backend: BACKEND, adapter=None) -> Type[BaseQuantLinear]:
     """utils/model.py:282-370: replace every module named in quant_result by an (empty) linear_cls instance"""
     named = dict(module.named_modules())
+    # validate EVERY module before swapping any: a NotImplementedError (the caller's cue to try the next candidate class,
+    # utils/model.py:234-239) must leave the model untouched
+    todo = []
     for name, res in quant_result.items():
         lin = named[name]
         if isinstance(lin, linear_cls):
             continue
         in_f, out_f = _features(lin)
-        nnz = 0 if res.get("ganq_outliers") is None else int(res["ganq_outliers"][1].numel())
         ok, err = linear_cls.validate(bits=res.get("bits", bits), group_size=group_size, desc_act=desc_act, sym=sym,
                                       in_features=in_f, out_features=out_f, pack_dtype=pack_dtype, device=device)
         if not ok:
-            raise err  # NotImplementedError: the caller falls through to the next candidate (utils/model.py:234-239)
-        new = linear_cls(bits=res.get("bits", bits), group_size=group_size, desc_act=desc_act, sym=sym, in_features=in_f,
-                         out_features=out_f, pack_dtype=pack_dtype, bias=lin.bias is not None, name=name,
-                         lm_head_name=lm_head_name, backend=backend, adapter=adapter, outliers=nnz).to(lin.weight.device)
-        new._packed_from = lin  # the quantized nn.Linear, until pack_module has consumed it
-        parent, _, child = name.rpartition(".")
-        setattr(named[parent] if parent else module, child, new)
+            raise err
+        todo.append((name, res, lin, in_f, out_f))
+    swapped = []
+    try:
+        for name, res, lin, in_f, out_f in todo:
+            nnz = 0 if res.get("ganq_outliers") is None else int(res["ganq_outliers"][1].numel())
+            new = linear_cls(bits=res.get("bits", bits), group_size=group_size, desc_act=desc_act, sym=sym, in_features=in_f,
+                             out_features=out_f, pack_dtype=pack_dtype, bias=lin.bias is not None, name=name,
+                             lm_head_name=lm_head_name, backend=backend, adapter=adapter, outliers=nnz).to(lin.weight.device)
+            # the quantized nn.Linear, until pack_module has consumed it.  Not through nn.Module.__setattr__: that would register
+            # it as a submodule of the new layer (named_modules / state_dict / parameters would carry the fp weights twice)
+            object.__setattr__(new, "_packed_from", lin)
+            parent, _, child = name.rpartition(".")
+            owner = named[parent] if parent else module
+            setattr(owner, child, new)
+            swapped.append((owner, child, lin))
+    except BaseException:
+        for owner, child, lin in swapped:  # a constructor failed midway: put the original modules back
+            setattr(owner, child, lin)
+        raise
     return linear_cls
 
 
@@ -125,7 +140,7 @@ def pack_module(name: str, qmodules: Dict[str, BaseQuantLinear], quant_result: D
     q = qmodules[name]
     q.pack(q._packed_from, r["scale"], r["zero"], r["g_idx"], ganq_indices=r["ganq_q"], ganq_codebook=r["ganq_lut"],
            ganq_outliers=r.get("ganq_outliers"))
-    del q._packed_from
+    object.__delattr__(q, "_packed_from")
 
 
 def pack_model(model: nn.Module, quant_result: Dict[str, Dict[str, Any]], qcfg, backend: BACKEND = BACKEND.AUTO,

@@ -80,6 +80,9 @@ class QuantizeConfig:
     ganq_outlier_ratio: float = field(default=0.0)
     # not in the reference: calibration batches are handed to the Hessian kernel in groups of up to this many tokens
     # (one read-modify-write of H per group instead of per batch; same H up to fp32 summation order).  0 = per batch.
+    # Memory: one buffer of this many tokens x in_features activations per hooked module while its group's calibration
+    # passes run (134 MB at in_features 4096, 470 MB at 14336; at most quantization.gptq.STAGE_MAX_LIVE per device, freed
+    # when the passes end).
     ganq_hessian_stage_tokens: int = field(default=16384)
 
     def __post_init__(self):

@@ -25,6 +25,11 @@ from .quantizer import HF_OPTIMUM, Quantizer
 
 
 _SIDE_STREAMS = {}
+# Hessian staging buffers alive per device (see GPTQ.__init__): each is stage_tokens x in_features activations (134 MB at
+# n = 4096, 470 MB at 14336).  A group of E mixture-of-experts modules would hold E of them through its forward passes; beyond
+# this many live buffers on a device a task accumulates batch by batch instead (same H up to fp32 summation order).
+_STAGE_LIVE = {}
+STAGE_MAX_LIVE = 8
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -105,8 +110,10 @@ class GPTQ:
             if self.hessian_stage_tokens > 0 and rows < self.hessian_stage_tokens:
                 if self._stage is not None and (self._stage.dtype != inp.dtype or self._stage_rows + rows > self._stage.shape[0]):
                     self._flush_stage()
-                if self._stage is None or self._stage.dtype != inp.dtype:
-                    self._stage = torch.empty((self.hessian_stage_tokens, self.columns), dtype=inp.dtype, device=self.device)
+                if (self._stage is None or self._stage.dtype != inp.dtype) and not self._stage_acquire(inp.dtype):
+                    _lib.hessian_accum(self.H, inp, self.nsamples, batch)  # the device already holds STAGE_MAX_LIVE buffers
+                    self.nsamples += batch
+                    return
                 self._stage[self._stage_rows:self._stage_rows + rows].copy_(inp)
                 self._stage_rows += rows
                 self._stage_seqs += batch
@@ -122,6 +129,30 @@ class GPTQ:
             upd = _lib.matmul_f32(x.t().contiguous(), x)
             self.H.mul_(self.nsamples / total).add_(upd, alpha=2.0 / total)
         self.nsamples += batch
+
+    def _stage_acquire(self, dtype) -> bool:
+        """allocate this task's staging buffer unless the device already holds STAGE_MAX_LIVE of them"""
+        self._stage_release()
+        key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if _STAGE_LIVE.get(key, 0) >= STAGE_MAX_LIVE:
+            return False
+        self._stage = torch.empty((self.hessian_stage_tokens, self.columns), dtype=dtype, device=self.device)
+        _STAGE_LIVE[key] = _STAGE_LIVE.get(key, 0) + 1
+        return True
+
+    def _stage_release(self):
+        if self._stage is not None:
+            key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            _STAGE_LIVE[key] = max(0, _STAGE_LIVE.get(key, 0) - 1)
+            self._stage = None
+
+    def end_of_calibration(self):
+        """The looper calls this when the forward passes of the module's group are over: the staged batches go to the
+        Hessian kernel and the staging buffer is freed HERE, not at quantize() -- between the two the other modules of the
+        group are quantized, and a mixture-of-experts group would otherwise hold one buffer per expert all that time."""
+        if hasattr(self, "H"):
+            self._flush_stage()
+        self._stage_release()
 
     def _flush_stage(self):
         """send the staged calibration batches to the Hessian kernel as one group (see __init__)"""
@@ -189,9 +220,7 @@ class GPTQ:
         for inp in self.fwd_inputs_buffered_data:
             self.process_batch(inp)
         self.fwd_inputs_buffered_data = []
-        if hasattr(self, "H"):
-            self._flush_stage()
-        self._stage = None
+        self.end_of_calibration()
 
         if self.module_copy is None:
             W = self._clone_module()
@@ -346,7 +375,7 @@ class GPTQ:
         pass
 
     def free(self):
-        self._stage = None
+        self._stage_release()
         if hasattr(self, "H"):
             del self.H
         for name in ("quantizer", "module_copy", "module", "L", "Xxt", "Xxt_damped"):

@@ -80,8 +80,9 @@ def test_other_layouts(tmp_path):
 
     (tmp_path / "d").mkdir()
     with open(tmp_path / "d" / "train.txt", "w") as f:
-        f.write("one\ntwo words\n")
-    assert load_text_split(str(tmp_path / "d"), "train") == ["one", "two words"]
+        f.write("one\n\ntwo words\r\nlast")
+    # .txt: one record per line WITH its newline (the hub's wikitext-2-raw records end with "\n", blank-line records included)
+    assert load_text_split(str(tmp_path / "d"), "train") == ["one\n", "\n", "two words\n", "last"]
     with open(tmp_path / "d" / "test.jsonl", "w") as f:
         f.write(json.dumps({"text": "x y"}) + "\n")
     assert load_text_split(str(tmp_path / "d"), "test") == ["x y"]
