@@ -9,7 +9,10 @@
 //      The argmin is monotone in i, so each layer is solved position-by-position in "bit-reversed" levels:
 //      i = n-1 first (full scan by the whole workgroup), then i = hs-1 + t*2hs for hs = P/2, P/4, .., 1, each
 //      bounded by the argmins of its two already-solved neighbours i-hs and i+hs; nodes of a level are independent
-//      (groups of up to 64 lanes scan one node and reduce with leftmost-minimum tie-break);
+//      (groups of up to 64 lanes scan one node and reduce with leftmost-minimum tie-break).  Round 3, resident kernel: the
+//      argmin is also monotone in the number of clusters, opt[k-1][i] <= opt[k][i] (the cost is Monge), so the previous
+//      layer's argmin at the SAME position is a second lower bound -- it cuts the long ranges of the top levels, where a
+//      level costs its latency, by 3-10x and the candidates of a row by a fifth;
 //   4. backtrack, centroids = weighted means (ascending).
 #include "common.h"
 
@@ -84,7 +87,8 @@ __device__ __forceinline__ double km_cost4(double cwj, double cwxj, double cwxxj
 // order-independent, so who scans what does not change the result.
 __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* wcwx, const double* wcwxx, const double* wdp,
                                                int base, const double* icw, const double* icwx, const double* icwxx,
-                                               uint16_t* acur, double* dcur, int* ag, int t0, int t1, int hs, int n, int G) {
+                                               uint16_t* acur, double* dcur, int* ag, int t0, int t1, int hs, int n, int G,
+                                               const uint16_t* aprev = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int lg = tid & (G - 1);
     const int groups = KL_THREADS / G;
@@ -95,6 +99,7 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
         if (valid) {
             i = hs - 1 + t * 2 * hs;
             lo = (i - hs >= 0) ? (int)acur[i - hs] : 0;
+            if (aprev) lo = max(lo, (int)aprev[i]);  // opt[k-1][i] <= opt[k][i]
             const int right = (i + hs < n) ? (i + hs) : (n - 1);
             hi = max(lo, min(i, (int)acur[right]));
         }
@@ -205,11 +210,12 @@ __device__ __forceinline__ KmQueue km_queue_at(char* base, int cap) {
 // lose: more ranges end up in the queue pass (defaults stay at 12 everywhere).
 template <int CAP>
 __device__ __forceinline__ void km_level_balanced(const double* cw, const double* cwx, const double* cwxx, const double* dprev,
-                                                  uint16_t* acur, double* dcur, int* ag, int cnt, int hs, int n, const KmQueue& q) {
+                                                  uint16_t* acur, double* dcur, int* ag, int cnt, int hs, int n, const KmQueue& q,
+                                                  const uint16_t* aprev) {
     const int tid = threadIdx.x;
     for (int t = tid; t < cnt; t += KL_THREADS) {
         const int i = hs - 1 + t * 2 * hs;
-        const int lo = (i - hs >= 0) ? (int)acur[i - hs] : 0;
+        const int lo = max((i - hs >= 0) ? (int)acur[i - hs] : 0, (int)aprev[i]);
         const int right = (i + hs < n) ? (i + hs) : (n - 1);
         const int hi = max(lo, min(i, (int)acur[right]));
         const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
@@ -292,7 +298,7 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
 #define KM_R4_MIN (MINW == 8 ? 4 : 64)
 #endif
 __device__ __forceinline__ void km_level_r4(const double* cw, const double* cwx, const double* cwxx, const double* dprev, uint16_t* acur,
-                                            double* dcur, int* ag, int S, int n, double* red_c, int* red_j) {
+                                            double* dcur, int* ag, int S, int n, double* red_c, int* red_j, const uint16_t* aprev) {
     const int tid = threadIdx.x;
     const int T = (n - 1) / S;        // positions i = S - 1 + t S < n - 1
     const int cntU = T - T / 4;       // ... that are not solved yet
@@ -311,7 +317,7 @@ __device__ __forceinline__ void km_level_r4(const double* cw, const double* cwx,
         if (valid) {
             const int left = i - ((t & 3) + 1) * S;
             const int right = min(i + (3 - (t & 3)) * S, n - 1);
-            const int lo = left >= 0 ? (int)acur[left] : 0;
+            const int lo = max(left >= 0 ? (int)acur[left] : 0, (int)aprev[i]);
             const int hi = max(lo, min(i, (int)acur[right]));
             const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
             for (int j = lo + lg; j <= hi; j += G)
@@ -342,6 +348,39 @@ __device__ __forceinline__ void km_level_r4(const double* cw, const double* cwx,
     }
 }
 
+// Radix-16 level at the very top of a layer (round 3): with the cross-layer bound a position needs no solved neighbour on
+// its left -- [opt[k-1][i], min(i, opt[k][n-1])] is short enough (a few hundred candidates from the third layer on) -- so the
+// 15 positions S - 1 + t S, S = P / 16, are solved in ONE level, one wave each, instead of two radix-4 levels.
+#ifndef KM_TOP16
+#define KM_TOP16 1
+#endif
+__device__ __forceinline__ void km_level_top16(const double* cw, const double* cwx, const double* cwxx, const double* dprev, uint16_t* acur,
+                                               const uint16_t* aprev, double* dcur, int* ag, int S, int n) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int T = (n - 1) / S;  // positions i = S - 1 + t S < n - 1 (at most 15: one wave each)
+    if (wv < T) {
+        const int i = S - 1 + wv * S;
+        const int lo = (int)aprev[i];
+        const int hi = max(lo, min(i, (int)acur[n - 1]));
+        const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
+        double bc = INFINITY;
+        int bj = 0x7fffffff;
+        for (int j = lo + lane; j <= hi; j += 64)
+            km_better_asc(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oc = __shfl_xor(bc, off);
+            const int oj = __shfl_xor(bj, off);
+            km_better(bc, bj, oc, oj);
+        }
+        if (lane == 0) {
+            dcur[i] = bc;
+            ag[i] = bj;
+            acur[i] = (uint16_t)bj;
+        }
+    }
+    km_lds_barrier();
+}
+
 // MINW = waves per SIMD the register allocation must allow: 4 (one workgroup per CU) or 8 (two, when two rows' arrays
 // fit the LDS together: n <= 2.3 k)
 template <int MINW>
@@ -355,7 +394,8 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
     double* cwxx = cwx + n1;
     double* dprev = cwxx + n1;
     uint16_t* acur = reinterpret_cast<uint16_t*>(dprev + n1);  // [n] argmins of the layer being solved
-    const KmQueue kq = km_queue_at(km_smem + align_up(4 * (size_t)n1 * sizeof(double) + (size_t)n * sizeof(uint16_t), 16), qcap);
+    uint16_t* aprev = acur + n;                                 // [n] ... of the layer before (they swap per layer)
+    const KmQueue kq = km_queue_at(km_smem + align_up(4 * (size_t)n1 * sizeof(double) + 2 * (size_t)n * sizeof(uint16_t), 16), qcap);
     uint64_t* keys = reinterpret_cast<uint64_t*>(km_smem);     // [P] during the sort only (8P <= 16(n+1): over cw, cwx)
     double* ctot = dprev;                                       // [3][nchunk] during the prefix sums only
     __shared__ double red_c[KL_THREADS / 64];
@@ -470,10 +510,16 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
         for (int i = tid; i < n; i += KL_THREADS) {
             dcur[i] = km_cost4(cw[0], cwx[0], cwxx[0], cw[i + 1], cwx[i + 1], cwxx[i + 1]);
             arg[i] = 0;
+            acur[i] = 0;  // layer 0: one cluster, every argmin is 0
         }
         __syncthreads();
         for (int k = 1; k < V; ++k) {
             __syncthreads();  // full barrier: D[k-1] (global) of every thread is complete
+            {   // the finished layer's argmins become the lower bounds of this one
+                uint16_t* tmp = aprev;
+                aprev = acur;
+                acur = tmp;
+            }
             for (int j = tid; j <= n; j += KL_THREADS) dprev[j] = (j == 0) ? 0.0 : dcur[j - 1];
             km_lds_barrier();
             KM_STAMP(2);
@@ -483,7 +529,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                 const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
                 double bc = INFINITY;
                 int bj = 0x7fffffff;
-                for (int j = tid; j <= i; j += KL_THREADS)
+                for (int j = (int)aprev[i] + tid; j <= i; j += KL_THREADS)
                     km_better_asc(bc, bj, dprev[j] + km_cost4(cw[j], cwx[j], cwxx[j], ci, cxi, cxxi), j);
                 for (int off = 32; off > 0; off >>= 1) {
                     const double oc = __shfl_xor(bc, off);
@@ -506,9 +552,14 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
             KM_STAMP(3);
             if (k == V - 1) break;  // only D[V-1][n-1] is needed from the last layer
             int sp = P;  // spacing of the solved positions (sp - 1 + t sp, and n - 1)
+            if (KM_TOP16 && P >= 1024 && (P >> 4) >= KM_R4_MIN) {  // (n - 1) / (P / 16) <= 15 positions, 16 waves
+                sp = P >> 4;
+                km_level_top16(cw, cwx, cwxx, dprev, acur, aprev, dcur, ag, sp, n);
+                KM_STAMP(4 + (31 - __builtin_clz(sp)));
+            }
             while ((sp >> 2) >= KM_R4_MIN) {  // radix-4 steps at the top
                 sp >>= 2;
-                km_level_r4(cw, cwx, cwxx, dprev, acur, dcur, ag, sp, n, red_c, red_j);
+                km_level_r4(cw, cwx, cwxx, dprev, acur, dcur, ag, sp, n, red_c, red_j, aprev);
                 KM_STAMP(4 + (31 - __builtin_clz(sp)));
             }
             for (int hs = sp >> 1; hs >= 1; hs >>= 1) {
@@ -518,12 +569,12 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                 while (G < KL_THREADS && G * 2 * cnt <= KL_THREADS) G <<= 1;
                 const int lg = tid & (G - 1);
                 if (cnt >= KB_MIN_NODES) {
-                    if (hs == 1) km_level_balanced<KB_CAP_1>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
-                    else if (hs == 2) km_level_balanced<KB_CAP_2>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
-                    else if (hs == 4) km_level_balanced<KB_CAP_4>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
-                    else km_level_balanced<KB_CAP>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq);
+                    if (hs == 1) km_level_balanced<KB_CAP_1>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq, aprev);
+                    else if (hs == 2) km_level_balanced<KB_CAP_2>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq, aprev);
+                    else if (hs == 4) km_level_balanced<KB_CAP_4>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq, aprev);
+                    else km_level_balanced<KB_CAP>(cw, cwx, cwxx, dprev, acur, dcur, ag, cnt, hs, n, kq, aprev);
                 } else if (G <= 64) {
-                    km_level_nodes(cw, cwx, cwxx, dprev, 0, cw, cwx, cwxx, acur, dcur, ag, 0, cnt - 1, hs, n, G);
+                    km_level_nodes(cw, cwx, cwxx, dprev, 0, cw, cwx, cwxx, acur, dcur, ag, 0, cnt - 1, hs, n, G, aprev);
                     km_lds_barrier();
                 } else {
                     // few nodes: several waves per node, partial minima through LDS
@@ -532,7 +583,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                     double bc = INFINITY;
                     int bj = 0x7fffffff;
                     if (t < cnt) {
-                        const int lo = (i - hs >= 0) ? (int)acur[i - hs] : 0;
+                        const int lo = max((i - hs >= 0) ? (int)acur[i - hs] : 0, (int)aprev[i]);
                         const int right = (i + hs < n) ? (i + hs) : (n - 1);
                         const int hi = max(lo, min(i, (int)acur[right]));
                         const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
@@ -872,7 +923,13 @@ static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
     p.Wcap = 0;
     const size_t acur_bytes = align_up((size_t)n * sizeof(uint16_t), 16);
     p.qcap = km_queue_cap(n);
-    const size_t lds_bytes = align_up(4 * (size_t)(n + 1) * sizeof(double) + (size_t)n * sizeof(uint16_t), 16) + km_queue_bytes(p.qcap);
+    // the second argmin array (round 3) is paid for by a shorter queue: first to keep TWO rows per CU where the arrays allow
+    // it at all (n <= 2.3 k), otherwise to stay inside the LDS with one
+    const size_t arrays = align_up(4 * (size_t)(n + 1) * sizeof(double) + 2 * (size_t)n * sizeof(uint16_t), 16);
+    const size_t half_budget = (KM_LDS_BUDGET + 1024) / 2 - 1024;
+    const size_t target = arrays + km_queue_bytes(128) <= half_budget ? half_budget : KM_LDS_BUDGET;
+    while (arrays + km_queue_bytes(p.qcap) > target && p.qcap > 128) p.qcap -= 64;
+    const size_t lds_bytes = arrays + km_queue_bytes(p.qcap);
     p.lds = lds_bytes <= KM_LDS_BUDGET;
     const int forced = (int)opt_get(OPT_KMEANS_WCAP);  // testing: force the windowed kernel with a small window
     if (forced > 0) p.lds = false;
