@@ -3,6 +3,7 @@
 //   synchronisation: the "is this iteration the best so far" decision and the conditional copies run on
 //   the device.
 #include <cmath>
+#include <mutex>
 
 #include "common.h"
 #include "solve_s.h"
@@ -74,6 +75,38 @@ static int launch_copy_if(const int32_t* flag, const void* src, void* dst, size_
     return 0;
 }
 
+// One helper stream + two events per (device, caller stream), created on first use (the pattern of cholesky.hip): the
+// iteration-invariant preparation of the T-update (fixed-point planes of H, W @ H) needs nothing of the first S-solve and
+// the first S-solve nothing of it, so the two CAN be enqueued side by side: GANQ_PREP_OVERLAP=1.  Measured without a gain at
+// 4096 x 4096 (see runtime.hip), so the default keeps one stream.
+struct PrepSide {
+    hipStream_t side;
+    hipEvent_t fork, join;
+};
+static PrepSide* prep_side_for(hipStream_t main) {
+    struct Slot {
+        int dev;
+        hipStream_t main;
+        PrepSide ps;
+    };
+    static Slot slots[32];
+    static int used = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (opt_get(OPT_PREP_OVERLAP) == 0 || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (slots[i].dev == dev && slots[i].main == main) return &slots[i].ps;
+    if (used == 32) return nullptr;  // more caller streams than slots: plain single-stream sequence
+    PrepSide ps{};
+    if (hipStreamCreateWithFlags(&ps.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ps.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ps.join, hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+    slots[used] = Slot{dev, main, ps};
+    return &slots[used++].ps;
+}
+
 struct RunLayout {
     size_t off_t0, off_t1, off_q, off_solve, off_upd, off_best, off_flag, total;
     size_t solve_bytes;
@@ -139,9 +172,16 @@ static int run_layer_impl(const float* W, const float* H, const float* L, int64_
     uint8_t* Qwork = alias ? Q_out : Qc;
 
     if (rcond < 0) rcond = 1.1920928955078125e-07 * (double)V;
-    // iteration-invariant part of the T-update / loss: fixed-point planes of H, W @ H and w^T H w in fp64 (ganq.py:590)
-    rc = t_prepare(W, H, m, n, lo.t, ws + lo.off_upd, true, stream);
+    // iteration-invariant part of the T-update / loss: fixed-point planes of H, W @ H and w^T H w in fp64 (ganq.py:590);
+    // on the helper stream, beside the first S-solve (joined before the first T-update)
+    PrepSide* ps = profile_enabled(KID_T_PREP) ? nullptr : prep_side_for(stream);  // per-kernel timing wants one stream
+    if (ps) {
+        GANQ_HIP_CHECK(hipEventRecord(ps->fork, stream));
+        GANQ_HIP_CHECK(hipStreamWaitEvent(ps->side, ps->fork, 0));
+    }
+    rc = t_prepare(W, H, m, n, lo.t, ws + lo.off_upd, true, ps ? ps->side : stream);
     if (rc) return rc;
+    if (ps) GANQ_HIP_CHECK(hipEventRecord(ps->join, ps->side));
     GANQ_HIP_CHECK(hipMemcpyAsync(Tc, T0, (size_t)m * V * sizeof(float), hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(best_init_kernel, dim3(1), dim3(1), 0, stream, best, best_k, flag);
     GANQ_LAUNCH_CHECK();
@@ -155,6 +195,7 @@ static int run_layer_impl(const float* W, const float* H, const float* L, int64_
     for (int k = 0; k < K; ++k) {
         rc = solve_s_launch(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, stream, rowlist, nactive);
         if (rc) return rc;
+        if (k == 0 && ps) GANQ_HIP_CHECK(hipStreamWaitEvent(stream, ps->join, 0));
         // new codebook and, from the same A and b, the loss of (new codebook, these indices)  (ganq.py:589-591, :621-622)
         rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, 1, nullptr, k, stream);
         if (rc) return rc;
