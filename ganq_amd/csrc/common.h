@@ -63,6 +63,7 @@ enum Opt : int {
     OPT_SOLVE_VARIANT,
     OPT_LUT_NT,
     OPT_LUT_GEMM_RM,
+    OPT_LUT_GEMM_PIPE,
     OPT_PREP_OVERLAP,
     OPT_COUNT
 };

@@ -41,6 +41,7 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"GANQ_SOLVE_VARIANT", 0},     // S-solve scheduling variant (developer A/B)
     {"GANQ_LUT_NT", 0},            // LUT decode kernel: force 1 / 2 tiles of 16 features per workgroup (0: by shape)
     {"GANQ_LUT_GEMM_RM", 0},       // LUT GEMM (M > 64): force this split factor of in_features (0: by shape)
+    {"GANQ_LUT_GEMM_PIPE", -1},    // LUT GEMM: 1 force / 0 forbid the one-workgroup-per-CU pipelined kernel (-1: by tile count)
     {"GANQ_PREP_OVERLAP", 0},      // fused loop: 1 = the T-update's preparation on a helper stream beside the first S-solve (measured:
                                    // 4096^2 14.13 -> 14.28 ms, 1024x4096 9.90 -> 9.87, 768x3072 6.36 -> 6.29: the S-solve holds 130 KB of
                                    // every CU's LDS, what runs beside it runs on its issue slots; off)

@@ -123,3 +123,23 @@ def test_lut_gemm_split_k_is_deterministic_and_matches(hip, ks):
         hip.debug_option("GANQ_LUT_GEMM_RM", None)
     # the shape-driven plan splits this one too (3 x 5 tiles)
     assert torch.allclose(hip.lut_linear(x, qw, lut, bias, 4).float(), y.float(), rtol=2 ** -9, atol=1e-3)
+
+
+@pytest.mark.parametrize("bits,M,dtype,m,n", [(4, 300, torch.float16, 384, 1024), (3, 257, torch.bfloat16, 200, 2048),
+                                              (2, 512, torch.float16, 128, 96), (4, 1000, torch.float16, 1025, 160)])
+def test_lut_gemm_pipelined_kernel_forced(hip, bits, M, dtype, m, n):
+    """the one-workgroup-per-CU pipelined kernel (taken by shape for >= 224 whole-K tiles) forced on small problems: odd stage
+    counts, ragged last stage, ragged rows / features; equal to the other kernel to rounding, to the fp64 bound"""
+    Q, lut, x, bias = make(bits, M, m, n, dtype, 77 + M)
+    qw = hip.pack_indices(Q, bits)
+    try:
+        hip.debug_option("GANQ_LUT_GEMM_RM", 1)  # no split-K: the switch below only applies to whole-K launches
+        hip.debug_option("GANQ_LUT_GEMM_PIPE", 1)
+        y1 = hip.lut_linear(x, qw, lut, bias, bits)
+        hip.debug_option("GANQ_LUT_GEMM_PIPE", 0)
+        y0 = hip.lut_linear(x, qw, lut, bias, bits)
+    finally:
+        hip.debug_option("GANQ_LUT_GEMM_PIPE", None)
+        hip.debug_option("GANQ_LUT_GEMM_RM", None)
+    check(y1, x, Q, lut, bias, dtype)
+    assert torch.equal(y0, y1)  # same products, same accumulation order per output: identical bits

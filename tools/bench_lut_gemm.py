@@ -44,10 +44,15 @@ def bench(m, n, M, bits=4, dtype=torch.float16):
     qw = _lib.pack_indices(Q, bits)
     Wq = _lib.lut_dequant(qw, lut, n, bits)
     t_lut = graph_time(lambda: _lib.lut_linear(x, qw, lut, None, bits))
+    t_v = {}
+    for pipe in (0, 1):  # the two whole-K kernels, forced (split-K launches ignore the switch)
+        _lib.debug_option("GANQ_LUT_GEMM_PIPE", pipe)
+        t_v[pipe] = graph_time(lambda: _lib.lut_linear(x, qw, lut, None, bits))
+    _lib.debug_option("GANQ_LUT_GEMM_PIPE", None)
     t_lib = graph_time(lambda: torch.nn.functional.linear(x, Wq))
     t_deq = graph_time(lambda: torch.nn.functional.linear(x, _lib.lut_dequant(qw, lut, n, bits)))
     flop = 2.0 * M * m * n
-    return {"out_x_in": f"{m}x{n}", "M": M, "bits": bits, "lut_gemm_us": round(t_lut, 1), "lib_fp16_gemm_us": round(t_lib, 1),
+    return {"out_x_in": f"{m}x{n}", "M": M, "bits": bits, "lut_gemm_us": round(t_lut, 1), "two_per_cu_us": round(t_v[0], 1), "pipelined_us": round(t_v[1], 1), "lib_fp16_gemm_us": round(t_lib, 1),
             "dequant_plus_lib_us": round(t_deq, 1), "lut_gemm_TFLOPs": round(flop / t_lut / 1e6, 1),
             "lib_TFLOPs": round(flop / t_lib / 1e6, 1), "vs_lib": round(t_lib / t_lut, 3), "vs_dequant_plus_lib": round(t_deq / t_lut, 3)}
 
