@@ -27,7 +27,15 @@ constexpr int HT = 128;       // output tile edge
 #endif
 constexpr int HK = HESS_HK;   // tokens per slab
 constexpr int HL = HK / 16;   // 16-byte loads per thread, operand and slab (256 threads x 16 B = 16 tokens x 128 features)
-constexpr int HP = HT + 8;    // LDS row pitch in 16-bit elements (272 B, multiple of 8 B)
+// LDS row pitch in 16-bit elements: 320 B.  A transposed fragment read (ds_read_b64_tr_b16) is served in two groups of 32
+// lanes; a group touches 4 consecutive token rows x 64 contiguous bytes (16 banks of 4 B), so it is conflict-free exactly when
+// consecutive rows start 16 banks apart: pitch = 64 B (mod 256 B).  Rounds 1-2 used 272 B (rows 4 banks apart): the SQ counters
+// showed 60 % of the kernel's LDS cycles as bank conflicts (SQ_LDS_BANK_CONFLICT 104 M of SQ_LDS_IDX_ACTIVE 174 M per
+// 16384 x 4096 launch) and a third of the wave cycles stalled on LDS issue.
+#ifndef HESS_PITCH_PAD
+#define HESS_PITCH_PAD 32
+#endif
+constexpr int HP = HT + HESS_PITCH_PAD;
 
 typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short s8v __attribute__((ext_vector_type(8)));
