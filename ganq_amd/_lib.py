@@ -35,6 +35,10 @@ SIGNATURES = {
     "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp]),
     "ganq_cholesky_workspace_bytes": (_c_sz, [_c_i64]),
     "ganq_cholesky": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "ganq_prologue_rowstats": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp]),
+    "ganq_prologue_gather": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int, _c_vp,
+                                            _c_vp, ctypes.c_int, _c_vp]),
+    "ganq_prologue_weights": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp]),
     "ganq_kmeans_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
     "ganq_kmeans_init": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_solve_s_workspace_bytes": (_c_sz, [_c_i64, _c_i64, ctypes.c_int]),
@@ -425,6 +429,70 @@ def cholesky(H, check: bool = True):
     if bad:
         raise torch.linalg.LinAlgError(f"ganq_cholesky: the input is not positive-definite (leading minor of order {bad})")
     return L
+
+
+def cholesky_inplace(A, check: bool = True):
+    """ganq_cholesky on A itself (fp32 [n,n], contiguous rows): the lower factor replaces A, the strict upper part is zeroed.
+    -> A, or (A, info tensor) with check=False"""
+    if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.shape[0] == A.shape[1] and A.stride(1) == 1):
+        raise GanqHipError("cholesky_inplace: a square fp32 cuda matrix with contiguous rows expected")
+    n = A.shape[0]
+    info = torch.zeros((), dtype=torch.int32, device=A.device)
+    ws = _workspace(lib().ganq_cholesky_workspace_bytes(n), A.device)
+    _call("ganq_cholesky", (A, info, ws), A.data_ptr(), n, A.stride(0) if n else 0, info.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
+    if not check:
+        return A, info
+    bad = int(info)
+    if bad:
+        raise torch.linalg.LinAlgError(f"ganq_cholesky: the input is not positive-definite (leading minor of order {bad})")
+    return A
+
+
+def prologue_rowstats(H):
+    """gptq.py:267-269,289-291 in one read of H -> (diag [n], rowabs [n] = sum_j |H[i][j]|), fp32"""
+    H = _dev_f32(H, "H")
+    n = H.shape[0]
+    diag = torch.empty((n,), dtype=torch.float32, device=H.device)
+    rowabs = torch.empty((n,), dtype=torch.float32, device=H.device)
+    _call("ganq_prologue_rowstats", (H, diag, rowabs), H.data_ptr(), n, diag.data_ptr(), rowabs.data_ptr(), _ST)
+    return diag, rowabs
+
+
+def prologue_gather(H, perm, diag_fixed, outputs):
+    """One read of H, every output written directly: outputs = [(add [n] fp32 or None, flip: bool), ...] (up to three) ->
+    list of new [n,n] fp32 tensors, out[i][j] = H'[perm i][perm j] + (i == j ? add[i] : 0), index-reversed when flip;
+    H' = H with diag_fixed on its diagonal; perm int64 [n] or None."""
+    H = _dev_f32(H, "H")
+    n = H.shape[0]
+    if not 1 <= len(outputs) <= 3:
+        raise GanqHipError("prologue_gather: one to three outputs")
+    diag_fixed = _dev_f32(diag_fixed, "diag_fixed")
+    perm_c = None if perm is None else perm.to(device=H.device, dtype=torch.int64).contiguous()
+    outs, args, keep = [], [], [H, perm_c, diag_fixed]
+    for k in range(3):
+        if k < len(outputs):
+            add, flip = outputs[k]
+            add_c = None if add is None else _dev_f32(add, "add")
+            o = torch.empty((n, n), dtype=torch.float32, device=H.device)
+            outs.append(o)
+            keep += [o, add_c]
+            args += [o.data_ptr(), _ptr(add_c), 1 if flip else 0]
+        else:
+            args += [None, None, 0]
+    _call("ganq_prologue_gather", tuple(keep), H.data_ptr(), _ptr(perm_c), diag_fixed.data_ptr(), n, *args, _ST)
+    return outs
+
+
+def prologue_weights(W, perm, dead, mean_fill: bool):
+    """gptq.py:270-276,283: W_out[r][c] = dead[perm c] ? fill_r : W[r][perm c] (fill: 0, or the row mean over the live columns)"""
+    W = _dev_f32(W, "W")
+    m, n = W.shape
+    dead_c = dead.to(device=W.device, dtype=torch.uint8).contiguous()
+    perm_c = None if perm is None else perm.to(device=W.device, dtype=torch.int64).contiguous()
+    out = torch.empty((m, n), dtype=torch.float32, device=W.device)
+    _call("ganq_prologue_weights", (W, perm_c, dead_c, out), W.data_ptr(), _ptr(perm_c), dead_c.data_ptr(), m, n, 1 if mean_fill else 0,
+          out.data_ptr(), _ST)
+    return out
 
 
 def kmeans_init(W, col_weight, V: int):

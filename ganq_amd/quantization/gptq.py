@@ -8,8 +8,8 @@ Host-side mirror of gptqmodel/quantization/gptq.py:42-393 with the same public s
   * everything lives on the GPU; there is no CPU fallback (the module must be on a cuda device);
   * GPTQ's own uniform-grid column loop (gptq.py:164-236) is NOT part of this path: only the GANQ subclass
     implements `_perform_quantization_loop`.
-The dense factorizations (Cholesky, cholesky_inverse) are library LAPACK calls through torch on the device,
-as in the reference.
+With `ganq_prologue="hip"` (default) the prologue is three passes over the matrices (csrc/prologue.hip) and two in-place
+factorisations by csrc/cholesky.hip; `"torch"` keeps the reference's own op sequence on torch.linalg (A/B runs, tests).
 """
 import math
 import time
@@ -214,6 +214,125 @@ class GPTQ:
         from .. import _lib
         return _lib.cholesky(H)
 
+    def _prologue_hip(self, W, H):
+        """gptq.py:267-308 on the device in three passes over the matrices (csrc/prologue.hip) plus n-vector steps: one read
+        of H for its diagonal and absolute row sums; dead columns, act_sort permutation, ganq-style offset and damping decided
+        on n-vectors; one gather that writes `Xxt_damped`, the ganq-style factorisation input and the index-reversed damped
+        matrix (whose factor yields diag(Hinv): U = P L'^-1 P with P H P = L' L'^T, so diag(U)[i] = 1 / L'[n-1-i][n-1-i])
+        directly; one gather of W.  The two factorisations run in place on two streams.  The reference's undamped copy `Xxt`
+        (gptq.py:288) is not kept: nothing on this path reads it."""
+        c = self.qcfg
+        n = self.columns
+        dev = H.device
+        diag, rowabs = _lib.prologue_rowstats(H)
+        dead = diag == 0                                            # gptq.py:267
+        diag_fixed = torch.where(dead, torch.ones_like(diag), diag)  # gptq.py:268: H[dead, dead] = 1
+        rowabs = rowabs + dead.to(rowabs.dtype)                     # ... which adds |1| to those rows' sums
+        if c.dead not in ("zero", "mean"):
+            raise AssertionError(f"Unknown dead mode: {c.dead}")
+        perm = invperm = None
+        if c.act_sort != "none":
+            assert c.act_sort in ["asc", "desc"]
+            perm = torch.argsort(diag_fixed, descending=c.act_sort == "desc")  # gptq.py:282
+            invperm = torch.argsort(perm)
+        W = _lib.prologue_weights(W, perm, dead, mean_fill=c.dead == "mean")
+        ganq_style = c.l_damp_style == "ganq"
+        offset = None
+        if ganq_style:                                              # gptq.py:289-291
+            offset = (rowabs - 2 * diag_fixed).clamp(min=1e-8)
+            offset = offset if perm is None else offset[perm]
+        mean_diag = torch.mean(diag_fixed)                          # gptq.py:296: damp = damp_percent * mean(diag(H))
+        damp_percent = c.damp_percent
+        total_damp = torch.zeros((), dtype=torch.float32, device=dev)
+        cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        pending = None  # the ganq-style factor, running on the side stream
+        Hinv = None
+        first = True
+        while 1 > damp_percent > 0:
+            # every retry adds damp_percent * mean(diag) of the ALREADY damped matrix on top (gptq.py:294-316)
+            total_damp = total_damp + damp_percent * (mean_diag + total_damp)
+            add = total_damp.expand(n).contiguous()
+            outs = [(add, False), (add, True)]                      # Xxt_damped; its index-reversed copy
+            if ganq_style and first:
+                outs.append((offset, False))                        # H + diag(offset), undamped (gptq.py:291)
+            mats = _lib.prologue_gather(H, perm, diag_fixed, outs)
+            self.Xxt_damped, Hflip = mats[0], mats[1]
+            if ganq_style and first:
+                A1 = mats[2]
+                side.wait_stream(cur)
+                A1.record_stream(side)
+                with torch.cuda.stream(side):
+                    L1, info1 = _lib.cholesky_inplace(A1, check=False)
+                L1.record_stream(cur)
+                pending = (L1, info1)
+            first = False
+            try:
+                if not ganq_style:
+                    self.L = _lib.cholesky(self.Xxt_damped)          # gptq-style: the factor of the damped matrix (a copy)
+                Lr = _lib.cholesky_inplace(Hflip)
+                Hinv = torch.flip(1.0 / torch.diagonal(Lr), dims=(0,)).contiguous()  # 1-D: the diagonal only
+                break
+            except torch._C._LinAlgError as e:
+                if c.damp_auto_increment != 0:
+                    damp_percent += c.damp_auto_increment
+                else:
+                    raise e
+        if pending is not None:
+            L1, info1 = pending
+            cur.wait_stream(side)
+            if int(info1):
+                raise torch.linalg.LinAlgError("ganq_cholesky: H + diag(offset) is not positive-definite "
+                                               f"(leading minor of order {int(info1)})")
+            self.L = L1
+        self.Xxt = None
+        return W, dead, perm, invperm, Hinv, damp_percent
+
+    def _prologue_reference_ops(self, W, H):
+        """the reference's own op sequence (gptq.py:267-316) on torch -- `ganq_prologue="torch"`, and any quantizer that reads
+        more of Hinv than its diagonal"""
+        dead = torch.diag(H) == 0
+        H[dead, dead] = 1
+        if self.qcfg.dead == "zero":
+            W[:, dead] = 0
+        elif self.qcfg.dead == "mean":
+            W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
+        else:
+            assert False, f"Unknown dead mode: {self.qcfg.dead}"
+
+        perm = None
+        invperm = None
+        if self.qcfg.act_sort != "none":
+            assert self.qcfg.act_sort in ["asc", "desc"]
+            perm = torch.argsort(torch.diag(H), descending=self.qcfg.act_sort == "desc")
+            W = W[:, perm].contiguous()
+            H = H[perm][:, perm].contiguous()
+            invperm = torch.argsort(perm)
+
+        self.Xxt = H.clone()  # undamped
+        if self.qcfg.l_damp_style == "ganq":
+            offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
+            self.L = torch.linalg.cholesky(H + torch.diag(offset))
+
+        damp_percent = self.qcfg.damp_percent
+        Hinv = None
+        while 1 > damp_percent > 0:
+            try:
+                damp = damp_percent * torch.mean(torch.diag(H))
+                diag = torch.arange(self.columns, device=self.device)
+                H[diag, diag] += damp
+                self.Xxt_damped = H.clone()
+                L = torch.linalg.cholesky(H)
+                if self.qcfg.l_damp_style == "gptq":
+                    self.L = L.clone()
+                Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
+                break
+            except torch._C._LinAlgError as e:
+                if self.qcfg.damp_auto_increment != 0:
+                    damp_percent += self.qcfg.damp_auto_increment
+                else:
+                    raise e
+        return W, dead, perm, invperm, Hinv, damp_percent
+
     @torch.inference_mode()
     def quantize(self, blocksize=128):
         start = time.time()
@@ -235,12 +354,15 @@ class GPTQ:
         cached = getattr(self, "_leader_prologue", None)
         if cached is not None and cached["key"] == self._prologue_key():
             dead, perm, invperm = cached["dead"], cached["perm"], cached["invperm"]
-            if self.qcfg.dead == "zero":
-                W[:, dead] = 0
-            elif self.qcfg.dead == "mean":
-                W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
-            if perm is not None:
-                W = W[:, perm].contiguous()
+            if getattr(self.qcfg, "ganq_prologue", "torch") == "hip" and W.is_cuda:
+                W = _lib.prologue_weights(W, perm, dead, mean_fill=self.qcfg.dead == "mean")  # as the leader's own weights
+            else:
+                if self.qcfg.dead == "zero":
+                    W[:, dead] = 0
+                elif self.qcfg.dead == "mean":
+                    W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
+                if perm is not None:
+                    W = W[:, perm].contiguous()
             self.Xxt, self.L, self.Xxt_damped = cached["Xxt"], cached["L"], cached["Xxt_damped"]
             Hinv, damp_percent = cached["Hinv"], cached["damp_percent"]
             self.nsamples = cached["nsamples"]
@@ -249,77 +371,11 @@ class GPTQ:
                 raise RuntimeError("quantize(): this module follows a leader that has not been quantized (yet)")
             H = self.H
             del self.H
-            dead = torch.diag(H) == 0
-            H[dead, dead] = 1
-            if self.qcfg.dead == "zero":
-                W[:, dead] = 0
-            elif self.qcfg.dead == "mean":
-                W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
-            else:
-                assert False, f"Unknown dead mode: {self.qcfg.dead}"
-
-            perm = None
-            invperm = None
-            if self.qcfg.act_sort != "none":
-                assert self.qcfg.act_sort in ["asc", "desc"]
-                perm = torch.argsort(torch.diag(H), descending=self.qcfg.act_sort == "desc")
-                W = W[:, perm].contiguous()
-                H = H[perm][:, perm].contiguous()
-                invperm = torch.argsort(perm)
-
-            self.Xxt = H.clone()  # undamped
-            # the GANQ loop only reads diag(Hinv), which one factorisation of the index-reversed matrix gives (config.py)
             native = (getattr(self.qcfg, "ganq_prologue", "torch") == "hip" and self._needs_only_hinv_diag() and H.is_cuda)
-            chol = self._hip_cholesky if native else torch.linalg.cholesky
-            pending = None  # (factor, info, stream) of a factorisation running beside the main stream
-            if self.qcfg.l_damp_style == "ganq":
-                offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
-                if native:
-                    # the two factorisations of the prologue (this one and the one that yields diag(Hinv)) are
-                    # independent chains of small kernels: run this one on a second stream, beside the other
-                    from .. import _lib
-                    A1 = H + torch.diag(offset)
-                    cur, side = torch.cuda.current_stream(H.device), _side_stream(H.device)
-                    side.wait_stream(cur)
-                    A1.record_stream(side)
-                    with torch.cuda.stream(side):
-                        L1, info1 = _lib.cholesky(A1, check=False)
-                    L1.record_stream(cur)
-                    pending = (L1, info1, side)
-                else:
-                    self.L = chol(H + torch.diag(offset))
-
-            damp_percent = self.qcfg.damp_percent
-            Hinv = None
-            while 1 > damp_percent > 0:
-                try:
-                    damp = damp_percent * torch.mean(torch.diag(H))
-                    diag = torch.arange(self.columns, device=self.device)
-                    H[diag, diag] += damp
-                    self.Xxt_damped = H.clone()
-                    if native:
-                        if self.qcfg.l_damp_style == "gptq":
-                            self.L = chol(H)
-                        Lr = chol(torch.flip(H, dims=(0, 1)))
-                        Hinv = torch.flip(1.0 / torch.diagonal(Lr), dims=(0,)).contiguous()  # 1-D: the diagonal only
-                    else:
-                        L = torch.linalg.cholesky(H)
-                        if self.qcfg.l_damp_style == "gptq":
-                            self.L = L.clone()
-                        Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
-                    break
-                except torch._C._LinAlgError as e:
-                    if self.qcfg.damp_auto_increment != 0:
-                        damp_percent += self.qcfg.damp_auto_increment
-                    else:
-                        raise e
-            if pending is not None:
-                L1, info1, side = pending
-                torch.cuda.current_stream(H.device).wait_stream(side)
-                if int(info1):
-                    raise torch.linalg.LinAlgError("ganq_cholesky: H + diag(offset) is not positive-definite "
-                                                   f"(leading minor of order {int(info1)})")
-                self.L = L1
+            if native:
+                W, dead, perm, invperm, Hinv, damp_percent = self._prologue_hip(W, H)
+            else:
+                W, dead, perm, invperm, Hinv, damp_percent = self._prologue_reference_ops(W, H)
             if not (0 < damp_percent < 1):
                 raise ValueError(f"Quantization: `damp_percent` must between 0 and 1. current is {damp_percent}")
             followers = getattr(self, "_followers", [])

@@ -129,6 +129,22 @@ int ganq_run_layer_rows(const float* W, const float* H, const float* L, int64_t 
  * smallest distance, strict <, NaN never wins (ganq.py:625); -1 if no iteration wins. */
 int ganq_select_best(const double* loss_rows_all, int64_t m, int K, double* dists, int32_t* best_k, void* stream);
 
+/* ---- a2: prologue of GPTQ.quantize() (gptq.py:259-319) in three passes -- dead columns, act_sort permutation, ganq-style
+ * offset, damping and the inputs of the two factorisations; the n-vector steps between them (dead = diag == 0, argsort, offset,
+ * damp) stay with the host.
+ *   ganq_prologue_rowstats: diag[i] = H[i][i], rowabs[i] = sum_j |H[i][j]|                         (gptq.py:267-269, :289-291)
+ *   ganq_prologue_gather:   out_k[i][j] = H'[perm i][perm j] + (i == j ? add_k[i] : 0), index-reversed when flip_k; H' = H with
+ *                           diag_fixed on its diagonal (dead columns read 1, gptq.py:268); perm NULL = identity; any out_k / add_k
+ *                           may be NULL; outputs must not alias H                                   (gptq.py:281-308)
+ *   ganq_prologue_weights:  W_out[r][c] = dead[perm c] ? fill_r : W[r][perm c]; fill_r = 0 (mean_fill 0, dead="zero") or the
+ *                           row's mean over the live columns (dead="mean")                         (gptq.py:270-276, :283)      */
+int ganq_prologue_rowstats(const float* H, int64_t n, float* diag, float* rowabs, void* stream);
+int ganq_prologue_gather(const float* H, const int64_t* perm, const float* diag_fixed, int64_t n, float* out0, const float* add0,
+                         int flip0, float* out1, const float* add1, int flip1, float* out2, const float* add2, int flip2,
+                         void* stream);
+int ganq_prologue_weights(const float* W, const int64_t* perm, const uint8_t* dead, int64_t m, int64_t n, int mean_fill,
+                          float* W_out, void* stream);
+
 /* ---- a9: LUT-dequant linear forward (replaces FakeQuantLinear.forward, fake.py:88-89) -------
  * y[M,m] = x[M,n] @ dequant(qweight, lut)^T + bias.   dtype: 0 = fp16, 1 = bf16 (x, lut, bias, y).
  * qweight: indices packed `bits` per index along the in_features dimension in the GPTQ int32
