@@ -251,8 +251,54 @@ class _TimerCtx:
             self.t.stats[self.key] = self.t.stats.get(self.key, 0.0) + time.perf_counter() - self.t0
 
 
+class CollectiveTurns:
+    """Several modules of a group are quantized at the same time (worker threads, side streams) while every module's
+    exchange is a sequence of collectives: those must be ISSUED in the same order on every rank.  Module i's thread enters
+    `turn(i)` before its first collective and leaves it after the last; turns are granted in index order, so the order of
+    the collectives is the group's module order on every rank, whichever thread finishes its local work first.  A thread
+    that fails marks the object broken, which raises in the waiting ones instead of leaving them (and the other ranks)
+    hanging."""
+
+    def __init__(self):
+        import threading
+
+        self._cv = threading.Condition()
+        self._next = 0
+        self._broken = None
+
+    def turn(self, index: int):
+        return _Turn(self, index)
+
+    def fail(self, exc):
+        with self._cv:
+            if self._broken is None:
+                self._broken = exc
+            self._cv.notify_all()
+
+
+class _Turn:
+    def __init__(self, owner, index):
+        self.o, self.i = owner, index
+
+    def __enter__(self):
+        with self.o._cv:
+            while self.o._next != self.i and self.o._broken is None:
+                self.o._cv.wait()
+            if self.o._broken is not None:
+                raise RuntimeError(f"another module of the group failed: {self.o._broken!r}")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        with self.o._cv:
+            if et is not None and self.o._broken is None:
+                self.o._broken = ev
+            self.o._next = self.i + 1
+            self.o._cv.notify_all()
+        return False
+
+
 def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: float = -1.0, dist: Optional[Dist] = None,
-                          solver=None, t0_fn=None, stats: Optional[dict] = None):
+                          solver=None, t0_fn=None, stats: Optional[dict] = None, turn=None):
     """ganq.py:501-634 with the rows of W split over the ranks.  Every rank passes the FULL W (replicated) and gets the
     FULL (T_best, Q, dists, best_k) back.  T0: the full initial codebook (replicated), or None with
     `t0_fn(W_rows) -> T0_rows`: then the codebook initialisation (ganq.py:423-438, rows are independent) is sharded as
@@ -263,7 +309,11 @@ def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: floa
     per-row losses lets every rank form the K distances in the single-GPU summation order (ganq_select_best), so the
     best-of-K decision (ganq.py:621-626) and every returned bit equal the unsharded run's; then one all-gather of the
     chosen codebook rows and one of the index rows.
-    stats: optional dict; with stats["timing"] set, "kmeans_s" / "loop_s" / "collective_s" are added up in it."""
+    stats: optional dict; with stats["timing"] set, "kmeans_s" / "loop_s" / "collective_s" are added up in it.
+    turn: optional context manager (CollectiveTurns.turn(i)) entered around the exchange, when the modules of a group run
+    their local parts concurrently."""
+    import contextlib
+
     dist = dist or Dist.current()
     solver = solver or HipSolver()
     m, n = W.shape
@@ -287,16 +337,17 @@ def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: floa
         T_all = torch.zeros((K, 0, V), dtype=torch.float32, device=W.device)
         Q_last = torch.zeros((0, n), dtype=torch.uint8, device=W.device)
         Q_all = None if alias_q else torch.zeros((K, 0, n), dtype=torch.uint8, device=W.device)
-    with timer("collective_s"):
-        loss_all = allgather_rows(loss_loc, slices, 1, dist)  # K x m doubles: the only exchange the decision needs
-    dists, best_k_t = solver.select_best(loss_all)
-    best_k = int(best_k_t)
-    kk = best_k if best_k >= 0 else K - 1  # no iteration won (all NaN): the last codebook, like the single-GPU loop
-    T_loc = T_all[kk]
-    Q_loc = Q_last if (alias_q or best_k < 0) else Q_all[kk]
-    with timer("collective_s"):
-        T_full = allgather_rows(T_loc.contiguous(), slices, 0, dist)
-        Q_full = allgather_rows(Q_loc.contiguous(), slices, 0, dist)
+    with (turn if turn is not None else contextlib.nullcontext()):
+        with timer("collective_s"):
+            loss_all = allgather_rows(loss_loc, slices, 1, dist)  # K x m doubles: the only exchange the decision needs
+        dists, best_k_t = solver.select_best(loss_all)
+        best_k = int(best_k_t)
+        kk = best_k if best_k >= 0 else K - 1  # no iteration won (all NaN): the last codebook, like the single-GPU loop
+        T_loc = T_all[kk]
+        Q_loc = Q_last if (alias_q or best_k < 0) else Q_all[kk]
+        with timer("collective_s"):
+            T_full = allgather_rows(T_loc.contiguous(), slices, 0, dist)
+            Q_full = allgather_rows(Q_loc.contiguous(), slices, 0, dist)
     return T_full, Q_full, dists, best_k
 
 

@@ -20,6 +20,8 @@ With torch.distributed initialised ("looper dispatches layers over RCCL ranks", 
   * the quantization of a module is row-parallel: k-means, S-solve and T-update of rank r's row slice, one exchange of
     the K x m row losses for best-of-K, one all-gather of the chosen codebook rows / indices
     (GANQ.row_dist -> ganq_amd.distributed.run_layer_row_sharded).  The prologue (two factorisations) is replicated.
+    The followers of a group's shared prologue run their local parts beside the leader's as on one GPU; the exchanges are
+    issued in the group's module order on every rank (ganq_amd.distributed.CollectiveTurns).
 `dist_mode="modules"` is the coarser scheme of round 1: the modules of a group are dealt to the ranks
 (ganq_amd.distributed.assign), every rank forwards everything, owners broadcast their results.
 Either way every rank ends with identical quantized layers.
@@ -89,6 +91,7 @@ class ModuleLooper:
         if dist_mode not in ("rows", "modules", "none") or calibration not in ("allreduce", "broadcast"):
             raise ValueError(f"ModuleLooper: dist_mode={dist_mode!r} / calibration={calibration!r}")
         self.dist_mode, self.calibration = dist_mode, calibration
+        self._turns = None  # the CollectiveTurns of the row-sharded group being processed
         self.dist_stats = {"timing": False}  # set ["timing"] = True to have the exchange steps timed (adds synchronisation)
         self.processor = processor
         self.layers = layers
@@ -125,6 +128,8 @@ class ModuleLooper:
                         t.record_stream(main)
             except BaseException as e:  # re-raised on the caller's thread
                 errors.append(e)
+                if self._turns is not None:  # row-sharded group: do not leave the other modules waiting for this one's exchange
+                    self._turns.fail(e)
 
         def start_followers():
             shared = getattr(tasks[followers[0]], "_leader_prologue", None) or {}
@@ -143,6 +148,10 @@ class ModuleLooper:
         tasks[leaders[0]]._on_prologue_shared = start_followers
         try:
             self.processor.process(named[leaders[0]])
+        except BaseException as e:
+            if self._turns is not None:
+                self._turns.fail(e)  # the followers must not wait for the leader's turn at the exchange
+            raise
         finally:
             for th in threads:
                 th.join()
@@ -309,9 +318,19 @@ class ModuleLooper:
                         self.processor.skip(named[n])
                         continue
                     todo.append(n)
-                if sharded:  # the row-sharded loop has collectives inside: one module after the other, in one order
+                if sharded:
+                    # every module's row-sharded loop ends in collectives, which must be issued in ONE order on every rank:
+                    # the modules of a group still run their local parts (k-means + fused loop on the rank's rows) side by
+                    # side like on one GPU, and take turns, in `todo` order, for the exchange
+                    turns = gdist.CollectiveTurns()
+                    for ti, n in enumerate(todo):
+                        self.processor.tasks[n]._collective_turn = turns.turn(ti)
+                    self._turns = turns
+                    try:
+                        self._process_group(todo, named)
+                    finally:
+                        self._turns = None
                     for n in todo:
-                        self.processor.process(named[n])
                         for k, v in getattr(named[n], "state", {}).get("ganq_stats", {}).items():
                             if k.endswith("_s"):
                                 self.dist_stats[k] = self.dist_stats.get(k, 0.0) + v

@@ -79,6 +79,7 @@ class GANQ(GPTQ):
             stats = {"timing": bool(getattr(self, "time_collectives", False))}
             T, Q, dists, best_k = gdist.run_layer_row_sharded(
                 W, self.Xxt_damped, self.L, None, self.iterations, alias_q=alias, dist=rd, stats=stats,
+                turn=getattr(self, "_collective_turn", None),
                 t0_fn=lambda W_rows: self._initialize_codebook_kmeans(W_rows, Hinv, num_bits, W.device))
             self.ganq_stats.update({k: v for k, v in stats.items() if k != "timing"})
         else:
