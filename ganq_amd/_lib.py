@@ -597,6 +597,10 @@ def lut_linear_outliers(x, qweight, lut, bias, bits: int, rowptr, cols, vals):
     x, qweight, lut = x.contiguous(), qweight.contiguous(), lut.contiguous()
     M, n = x.shape
     m = lut.shape[0]
+    max_rows = ((1 << 31) - 1) // (2 * max(n, 1)) - 256  # see lut_linear
+    if M > max_rows:
+        step = max(256, max_rows // 256 * 256)
+        return torch.cat([lut_linear_outliers(x[r:r + step], qweight, lut, bias, bits, rowptr, cols, vals) for r in range(0, M, step)], dim=0)
     y = torch.empty((M, m), dtype=x.dtype, device=x.device)
     ws = _lut_workspace(lib().ganq_lut_linear_outliers_workspace_bytes(M, m, n, bits), x.device)
     _call("ganq_lut_linear_fwd_outliers", (x, qweight, lut, bias, rowptr, cols, vals, y, ws), x.data_ptr(), qweight.data_ptr(), lut.data_ptr(), _ptr(bias), rowptr.data_ptr(),
@@ -616,6 +620,12 @@ def lut_linear(x, qweight, lut, bias, bits: int, addend=None):
     x, qweight, lut = x.contiguous(), qweight.contiguous(), lut.contiguous()
     M, n = x.shape
     m = lut.shape[0]
+    # the GEMM kernels address x through 32-bit buffer offsets: more than ~2 GB of activations go in row chunks
+    max_rows = ((1 << 31) - 1) // (2 * max(n, 1)) - 256
+    if M > max_rows:
+        step = max(256, max_rows // 256 * 256)
+        return torch.cat([lut_linear(x[r:r + step], qweight, lut, bias, bits, None if addend is None else addend[r:r + step].contiguous())
+                          for r in range(0, M, step)], dim=0)
     y = torch.empty((M, m), dtype=x.dtype, device=x.device)
     ws = _lut_workspace(lib().ganq_lut_linear_workspace_bytes(M, m, n, bits), x.device)
     if addend is not None:

@@ -45,7 +45,7 @@ constexpr int GPITCH = 64 * GST + 16;  // bytes per LDS row (activations and dec
 // SPLIT: blockIdx.y = ks takes the stages [ks * st_per, (ks + 1) * st_per) of in_features and writes its fp32 partial tile;
 // lut_gemm_reduce_kernel, the next launch on the stream, sums the splits in ks order (deterministic), adds addend / bias and
 // rounds once.  Serves 64 < M <= ~1024, where whole-K tiles would leave CUs idle.
-template <int BITS, bool BF16, bool SPLIT>
+template <int BITS, bool BF16, bool SPLIT, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void lut_gemm_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                         const uint16_t* __restrict__ lut, const uint16_t* __restrict__ bias,
                                                         const float* __restrict__ addend, int M, int m, int n, int tiles_m,
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void lut_gemm_kernel(const uint16_t* __rest
     const int nst = SPLIT ? min(nst_all, st_begin + st_per) : nst_all;  // this workgroup's stages: [st_begin, nst)
 
     // ---- decode role: this thread's feature and octets
-    const int dfeat = tid & 127, dq0 = tid >> 7;  // octets dq0 and dq0 + 2 of every group
+    const int dfeat = tid & 127, dq0 = __builtin_amdgcn_readfirstlane(tid >> 7);  // octets dq0 and dq0 + 2 of every group (wave-uniform)
     const int dcol = min(o0 + dfeat, m - 1);
     if (wv < 2) {  // the codebook of feature o0 + 64 * wv + lane, one dword slot per entry and lane
         const uint32_t* lp = reinterpret_cast<const uint32_t*>(lut + (int64_t)dcol * V);
@@ -101,33 +101,40 @@ __global__ __launch_bounds__(256, 2) void lut_gemm_kernel(const uint16_t* __rest
 
     // ---- global -> register staging of one stage
     const int achunk = tid % TPR, arow0 = tid / TPR;  // rows arow0 + RPP * i
-    // rows past M are clamped, not zeroed: what they produce lands in accumulator rows that are never stored
-    const uint16_t* xrow[NLD];
+    // buffer loads: this thread's constant byte offsets in VGPRs, the stage's offset in an SGPR (no per-load 64-bit address
+    // arithmetic; the host takes the pointer-free path only while both operands stay below 2 GB); activation rows past M lie
+    // past the resource's end and read as zeros
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, (int)((int64_t)M * n * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(qw), 0, (int)((int64_t)(n >> 5) * BITS * m * 4), 0x00020000);
+    int xoff[NLD];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) xrow[i] = x + (int64_t)min(r0 + arow0 + RPP * i, M - 1) * n;
+    for (int i = 0; i < NLD; ++i) xoff[i] = ((r0 + arow0 + RPP * i) * n + 8 * achunk) * 2;
+    const int woff = dcol * 4;
     g_u32x4 xa[NLD];
     uint32_t wl[NIT], wh[NIT];  // item = (group g, octet dq0 + 2 j): index 2 g + j
     // nothing may touch the loaded registers here: a select right behind the loads makes the compiler wait for them on the
     // spot (measured: a third of the kernel's time); the columns of a ragged last stage are zeroed where the slab is stored
     auto gload = [&](int st) {
-        const int col = 32 * GST * st + 8 * achunk;  // first in_feature of this thread's chunk
-        const int colc = col < n ? col : 0;
+        const int soff = 64 * GST * st;  // bytes along a row
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) xa[i] = *reinterpret_cast<const g_u32x4*>(xrow[i] + colc);
+        for (int i = 0; i < NLD; ++i)
+            xa[i] = __builtin_bit_cast(g_u32x4, RAGGED ? __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[i] + soff, 0, 0)
+                                                      : __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[i], soff, 0));
 #pragma unroll
         for (int g = 0; g < GST; ++g) {
-            const int kb = min(GST * st + g, nkb - 1);
+            const int kb = RAGGED ? min(GST * st + g, nkb - 1) : GST * st + g;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                wl[2 * g + j] = qw[(int64_t)(kb * BITS + wi[j]) * m + dcol];
-                if (STRADDLE) wh[2 * g + j] = qw[(int64_t)(kb * BITS + wi2[j]) * m + dcol];
+                wl[2 * g + j] = __builtin_amdgcn_raw_buffer_load_b32(rsw, woff, (kb * BITS + wi[j]) * m * 4, 0);
+                if (STRADDLE) wh[2 * g + j] = __builtin_amdgcn_raw_buffer_load_b32(rsw, woff, (kb * BITS + wi2[j]) * m * 4, 0);
             }
         }
     };
     const uint32_t tb = (uint32_t)(uintptr_t)(&tbl[0][0][0]) + (uint32_t)(wv & 1) * (V * 256u);
     const uint32_t lane4 = 4u * lane;
     auto sstore = [&](int st) {  // registers -> LDS: the activation slab as it is, the weights decoded
-        const bool col_ok = 32 * GST * st + 8 * achunk < n;  // false only in a ragged last stage
+        const bool col_ok = !RAGGED || 32 * GST * st + 8 * achunk < n;  // in_features a multiple of 64: no select at all
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
             *reinterpret_cast<g_u32x4*>(As + (arow0 + RPP * i) * GPITCH + 16 * achunk) = col_ok ? xa[i] : g_u32x4{0u, 0u, 0u, 0u};
@@ -545,17 +552,27 @@ static int launch_gemm_bits(const void* x, const uint32_t* qw, const void* lut, 
     const uint16_t* bp = static_cast<const uint16_t*>(bias);
     uint16_t* yp = static_cast<uint16_t*>(y);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.KS);
-#define GANQ_GEMM_LAUNCH(BF, SP)                                                                                                 \
-    hipLaunchKernelGGL((lut_gemm_kernel<BITS, BF, SP>), grid, dim3(256), 0, stream, xp, qw, lp, bp, addend, M, m, n, p.tiles_m,  \
-                       p.tiles_n, yp, p.st_per, partial)
+#define GANQ_GEMM_LAUNCH(BF, SP)                                                                                                        \
+    do {                                                                                                                                \
+        if ((n & 63) != 0)                                                                                                              \
+            hipLaunchKernelGGL((lut_gemm_kernel<BITS, BF, SP, true>), grid, dim3(256), 0, stream, xp, qw, lp, bp, addend, M, m, n,      \
+                               p.tiles_m, p.tiles_n, yp, p.st_per, partial);                                                            \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((lut_gemm_kernel<BITS, BF, SP, false>), grid, dim3(256), 0, stream, xp, qw, lp, bp, addend, M, m, n,     \
+                               p.tiles_m, p.tiles_n, yp, p.st_per, partial);                                                            \
+    } while (0)
     const int pipe_opt = (int)opt_get(OPT_LUT_GEMM_PIPE);
-    // measured (4-bit, fp16): about one tile per CU (4096 x 4096, M = 2048: 256 tiles) 105 us pipelined vs 125 us with the
-    // two-workgroups-per-CU kernel; 512 tiles (M = 4096) 182 vs 172; 1792 tiles (14336 x 4096, M = 4096) 559 vs 592
+    // measured (4-bit, fp16, both kernels with buffer loads): about one tile per CU (4096 x 4096, M = 2048: 256 tiles) 87 us
+    // pipelined vs 103 us with the two-workgroups-per-CU kernel; 512 tiles (M = 4096) 175 vs 164; 896 tiles (14336 x 4096,
+    // M = 2048) 310 vs 287; 1792 tiles (M = 4096) 556 vs 520: the pipelined kernel where a CU gets one tile, the other above
     const int64_t ntile = (int64_t)p.tiles_m * p.tiles_n;
-    const bool pipe_by_shape = (ntile >= 224 && ntile < 448) || ntile >= 1024;
+    const bool pipe_by_shape = ntile >= 224 && ntile < 448;
     // the pipelined kernel addresses both operands through 32-bit buffer offsets (incl. one stage of look-ahead)
     const bool fits32 = ((int64_t)M + GBM) * n * 2 < (1ll << 31) && (int64_t)(n >> 5) * BITS * m * 4 < (1ll << 31);
-    const bool pipe = p.KS == 1 && fits32 && (pipe_opt >= 0 ? pipe_opt != 0 : pipe_by_shape);
+    if (!fits32)
+        return fail(-1, "ganq_lut_linear_fwd: x (%lld x %lld) or qweight beyond the 2 GB window of the GEMM's buffer loads: split the "
+                        "rows of x over several calls", (long long)M, (long long)n);
+    const bool pipe = p.KS == 1 && (pipe_opt >= 0 ? pipe_opt != 0 : pipe_by_shape);
     if (pipe) {
         const bool ragged = (n & 63) != 0;
 #define GANQ_PIPE_LAUNCH(BF, RG)                                                                                                   \
