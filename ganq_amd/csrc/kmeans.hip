@@ -649,8 +649,9 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
     double* wcwx = wcw + Wcap;
     double* wcwxx = wcwx + Wcap;
     double* wdp = wcwxx + Wcap;
-    uint16_t* acur = reinterpret_cast<uint16_t*>(wdp + Wcap);  // [n]
-    uint64_t* keys = reinterpret_cast<uint64_t*>(km_smem);     // [P] during the sort only (may run over acur)
+    uint16_t* acur = reinterpret_cast<uint16_t*>(wdp + Wcap);  // [n] argmins of the layer being solved
+    uint16_t* aprev = acur + n;                                 // [n] ... of the layer before: the cross-layer lower bound
+    uint64_t* keys = reinterpret_cast<uint64_t*>(km_smem);     // [P] during the sort only (may run over acur / aprev)
     double* ctot = reinterpret_cast<double*>(km_smem);         // [3][nchunk] during the prefix sums only
     __shared__ double red_c[KL_THREADS / 64];
     __shared__ int red_j[KL_THREADS / 64];
@@ -765,10 +766,17 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
             for (int i = tid; i < n; i += KL_THREADS) {
                 dbuf0[i] = km_cost4(c0, cx0, cxx0, cw[i + 1], cwx[i + 1], cwxx[i + 1]);
                 arg[i] = 0;
+                acur[i] = 0;  // layer 0: one cluster, every argmin is 0
             }
         }
         __syncthreads();
         for (int k = 1; k < V; ++k) {
+            {   // opt[k-1][i] <= opt[k][i]: the finished layer's argmins bound this one's ranges from below -- up here that
+                // also shrinks the windows that have to be staged (the top levels' ranges by 3-10x)
+                uint16_t* tmp = aprev;
+                aprev = acur;
+                acur = tmp;
+            }
             const double* dprev_g = (k & 1) ? dbuf0 : dbuf1;  // D[k-1]
             double* dcur = (k & 1) ? dbuf1 : dbuf0;
             int* ag = arg + (size_t)k * n;
@@ -812,13 +820,13 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
                 }
                 __syncthreads();
             };
-            solve_wide(n - 1, 0, n - 1);
+            solve_wide(n - 1, (int)aprev[n - 1], n - 1);
             if (k == V - 1) break;  // only D[V-1][n-1] is needed from the last layer
             for (int hs = P >> 1; hs >= 1; hs >>= 1) {
                 const int cnt = (n - 1 > hs - 1) ? ((n - 1 - (hs - 1) + 2 * hs - 1) / (2 * hs)) : 0;
                 auto node_lo = [&](int t) {
                     const int i = hs - 1 + t * 2 * hs;
-                    return (i - hs >= 0) ? (int)acur[i - hs] : 0;
+                    return max((i - hs >= 0) ? (int)acur[i - hs] : 0, (int)aprev[i]);
                 };
                 auto node_hi = [&](int t) {
                     const int i = hs - 1 + t * 2 * hs;
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
                     while (G < KL_THREADS && G * 2 * segcnt <= KL_THREADS) G <<= 1;
                     const int lg = tid & (G - 1);
                     if (G <= 64) {
-                        km_level_nodes(wcw, wcwx, wcwxx, wdp, base, cw, cwx, cwxx, acur, dcur, ag, t0, t1, hs, n, G);
+                        km_level_nodes(wcw, wcwx, wcwxx, wdp, base, cw, cwx, cwxx, acur, dcur, ag, t0, t1, hs, n, G, aprev);
                         __syncthreads();
                     } else {
                         const int t = t0 + tid / G;
@@ -921,7 +929,7 @@ static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
     p.P = 1;
     while (p.P < n) p.P <<= 1;
     p.Wcap = 0;
-    const size_t acur_bytes = align_up((size_t)n * sizeof(uint16_t), 16);
+    const size_t acur_bytes = align_up(2 * (size_t)n * sizeof(uint16_t), 16);  // the layer's argmins and the previous layer's
     p.qcap = km_queue_cap(n);
     // the second argmin array (round 3) is paid for by a shorter queue: first to keep TWO rows per CU where the arrays allow
     // it at all (n <= 2.3 k), otherwise to stay inside the LDS with one
