@@ -295,6 +295,39 @@ def test_looper_concurrent_followers_are_identical():
 
 
 @torch.no_grad()
+def test_looper_concurrent_followers_real_shapes_back_to_back():
+    """the same at Llama-3.2-1B's attention shapes (hidden 2048: q / k / v 2048 x 2048, three layers back to back, several
+    batches): followers on side streams read the leader's prologue tensors and hand their results to the main stream while
+    the caching allocator recycles blocks between modules and layers -- every result bit-identical to the sequential run"""
+    from ganq_amd.looper.gptq_processor import GPTQProcessor
+    from ganq_amd.looper.module_looper import ModuleLooper
+    from ganq_amd.quantization import QuantizeConfig
+
+    res, outs, logs = [], [], []
+    for conc in (False, True):
+        torch.manual_seed(0)
+        model = nn.Module()
+        model.layers = nn.ModuleList([ToyLayer(2048, 4096) for _ in range(3)])
+        model = model.half().cuda()
+        xs = [torch.randn(2, 256, 2048, device="cuda", generator=torch.Generator(device="cuda").manual_seed(30 + i)).half()
+              for i in range(4)]
+        proc = GPTQProcessor(QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", ganq_iterations=3))
+        out = ModuleLooper(proc, model.layers, [["q_proj", "k_proj", "v_proj"], ["out_proj"], ["fc1"], ["fc2"]],
+                           layers_prefix="layers", share_group_hessian=True, concurrent_group=conc).loop(xs)
+        torch.cuda.synchronize()
+        res.append({k: (v["ganq_q"].clone(), v["ganq_lut"].clone()) for k, v in proc.results().items()})
+        outs.append([o.clone() for o in out])
+        logs.append([(r["layer"], r["module"]) for r in proc.log])
+        del model, proc
+        torch.cuda.empty_cache()
+    assert len(res[0]) == 18 and res[0].keys() == res[1].keys()
+    assert logs[0] == logs[1]  # the log keeps the group's module order whichever thread finished first
+    for k in res[0]:
+        assert torch.equal(res[0][k][0], res[1][k][0]) and torch.equal(res[0][k][1], res[1][k][1]), k
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+@torch.no_grad()
 def test_looper_early_exit_is_identical():
     # stopping a group's calibration forward once its modules have seen the batch must not change any statistic
     from ganq_amd.looper.gptq_processor import GPTQProcessor
