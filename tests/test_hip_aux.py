@@ -305,3 +305,53 @@ def test_lut_linear_golden_forward(hip):
         y = hip.lut_linear(dev(g["x_fwd"]), qw, lut.cuda(), dev(g["bias"]), bits).cpu().float().numpy()
         ref = g["y_fwd"].astype(np.float32)
         assert np.allclose(y, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max()), name
+
+
+# ------------------------------------------------------------------------------------------ prologue passes
+@pytest.mark.parametrize("n,m,act_sort,dead_mode", [(96, 40, "asc", "mean"), (300, 64, "desc", "zero"), (1030, 33, "none", "mean"),
+                                                     (2048, 128, "asc", "mean")])
+def test_prologue_passes_match_the_reference_op_sequence(hip, n, m, act_sort, dead_mode):
+    """csrc/prologue.hip against the torch ops of gptq.py:267-300 they replace: dead columns, permutation gathers, ganq-style
+    offset, damping, index reversal -- everything but the row sums is data movement and must be bit-identical"""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    X = torch.randn(2 * n, n, device="cuda", generator=g) * (0.1 + torch.rand(n, device="cuda", generator=g))
+    X[:, 5] = 0
+    X[:, n - 3] = 0  # two dead columns
+    H = (X.T @ X) / n
+    W = torch.randn(m, n, device="cuda", generator=g)
+    diag, rowabs = hip.prologue_rowstats(H)
+    assert torch.equal(diag, torch.diag(H))
+    assert torch.allclose(rowabs, torch.sum(torch.abs(H), dim=1), rtol=1e-6)
+    dead = diag == 0
+    assert int(dead.sum()) == 2
+    # the reference's sequence
+    Hr, Wr = H.clone(), W.clone()
+    Hr[dead, dead] = 1
+    Wr[:, dead] = 0 if dead_mode == "zero" else torch.mean(Wr[:, ~dead], dim=1, keepdim=True)
+    perm = None
+    if act_sort != "none":
+        perm = torch.argsort(torch.diag(Hr), descending=act_sort == "desc")
+        Wr = Wr[:, perm]
+        Hr = Hr[perm][:, perm]
+    damp = 0.01 * torch.mean(torch.diag(Hr))
+    offset = (torch.sum(torch.abs(Hr), dim=1) - 2 * torch.diag(Hr)).clamp(min=1e-8)
+    # the passes
+    diag_fixed = torch.where(dead, torch.ones_like(diag), diag)
+    Wp = hip.prologue_weights(W, perm, dead, mean_fill=dead_mode == "mean")
+    if dead_mode == "zero":
+        assert torch.equal(Wp, Wr)
+    else:
+        live = ~(dead if perm is None else dead[perm])
+        assert torch.equal(Wp[:, live], Wr[:, live]) and torch.allclose(Wp, Wr, rtol=1e-6, atol=1e-7)
+    add = damp.expand(n).contiguous()
+    Xd, Hf, A1 = hip.prologue_gather(H, perm, diag_fixed, [(add, False), (add, True), (offset, False)])
+    eye = torch.eye(n, device="cuda", dtype=torch.bool)
+    want = Hr.clone()
+    want[eye] += damp
+    assert torch.equal(Xd, want)
+    assert torch.equal(Hf, torch.flip(want, dims=(0, 1)))
+    assert torch.equal(A1, Hr + torch.diag(offset))
+    # in-place factorisation == the copying one
+    L1 = hip.cholesky(A1)
+    L2 = hip.cholesky_inplace(A1.clone())
+    assert torch.equal(L1, L2)
