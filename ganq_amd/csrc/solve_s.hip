@@ -86,6 +86,7 @@ struct PanelState {
     uint32_t q[SKR];  // index captured at this lane's columns
     float tv;       // T[row][c16] (+inf beyond V)
     uint32_t c16;
+    uint32_t pad;   // all ones in the lanes beyond V: their distance key can never win (inf - inf there would be a NaN)
 };
 
 // ---- threshold form of the argmin (fast path of the panel steps) ---------------------------------------------------
@@ -287,7 +288,12 @@ __device__ __forceinline__ void panel_step(PanelState& st, const float2 dg, cons
     const float eff_l = st.w[KREG] + quo;
     const float eff = dpp_f<0x150 + OWN>(eff_l);  // row_newbcast: owner lane -> its 16-lane row
     const float wj = dpp_f<0x150 + OWN>(st.w[KREG]);
-    const uint32_t d = __builtin_bit_cast(uint32_t, eff - st.tv) & 0x7fffffffu;  // |eff - T[v]| as ordered bits
+    // |eff - T[v]| as ordered bits, shifted up by one so that key 0 is free for a NaN distance: torch.argmin (ganq.py:547)
+    // treats a NaN as smaller than everything and returns the first one (pinned by the reference golden
+    // tests/golden/large/nan48x256_b4_k1.npz); only this reduction path ever sees one -- a row with a NaN codebook entry
+    // never qualifies for the threshold path, and a NaN residual fails its range test
+    const uint32_t d0 = __builtin_bit_cast(uint32_t, eff - st.tv) & 0x7fffffffu;
+    const uint32_t d = (d0 > 0x7f800000u ? 0u : d0 + 1u) | st.pad;
     const uint32_t dmin = row_min_u(d);
     const uint32_t cand = (d == dmin) ? st.c16 : 255u;
     const uint32_t idx = row_min_u(cand);  // first minimum
@@ -655,6 +661,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     PanelState st;
     st.c16 = (uint32_t)c16;
     st.tv = (c16 < V) ? T[(int64_t)prow * V + c16] : __builtin_inff();
+    st.pad = (c16 < V) ? 0u : 0xffffffffu;
     float wnext[SKR] = {};
     // (P) threshold form of the argmin: sorted codebook, exact switch-over points (see FastRow); ErrPk is free until the
     // first panel has been solved and serves as the sort's scratch (32 dwords per 16-lane row)

@@ -53,7 +53,8 @@ void ganq_oracle_set_num_threads(int t) {
  *
  * For every row i independently, for j = n-1 .. 0:
  *     eff   = W[i,j] + r_j / L[j,j]                         ganq.py:540-542
- *     idx   = first argmin_s |eff - T[i,s]|  (strict <)     ganq.py:546-547, :107-123
+ *     idx   = first argmin_s |eff - T[i,s]|  (strict <; a NaN distance -- NaN codebook entry or residual -- counts as
+ *             smaller than everything, the first one wins: torch.argmin)          ganq.py:546-547, :107-123
  *     Q[i,j]= idx                                           ganq.py:550
  *     err_j = W[i,j] - T[i,idx]                             ganq.py:125-126 / :564-565
  *     r_c   = sum_{u>c} err_u * L[u,c]                      ganq.py:565 (column j-1 of L)
@@ -88,10 +89,15 @@ int ganq_oracle_solve_s(const float* W, const float* L, int64_t ldl, const float
                     float q = racc[j] / lrow[j];
                     float eff = w[j] + q;
                     float best = INFINITY;
-                    int idx = 0;
-                    for (int s = 0; s < V; ++s) {
+                    int idx = 0, have_nan = 0;
+                    for (int s = 0; s < V; ++s) {  /* torch.argmin (ganq.py:547): the first NaN wins, else the first minimum */
                         float d = fabsf(eff - t[s]);
-                        if (d < best) {
+                        if (d != d) {
+                            if (!have_nan) {
+                                have_nan = 1;
+                                idx = s;
+                            }
+                        } else if (!have_nan && d < best) {
                             best = d;
                             idx = s;
                         }

@@ -40,6 +40,9 @@ CASES = [
     dict(name="l128x2048_b4_k10", m=128, n=2048, bits=4, K=10, seed=202, tokens=4096, hash_only=False),
     dict(name="l256x512_b2_k3", m=256, n=512, bits=2, K=3, seed=204, tokens=2048, hash_only=False),
     dict(name="h4096x4096_b4_k2", m=4096, n=4096, bits=4, K=2, seed=203, tokens=8192, hash_only=True),
+    # torch.argmin's NaN semantics in the S-solve (ganq.py:547): two codebook entries are NaN; only the S-solve of the one
+    # iteration is captured (what lstsq / the loss make of NaN inputs is not part of the contract: gptq.py:328-330 raises)
+    dict(name="nan48x256_b4_k1", m=48, n=256, bits=4, K=1, seed=205, tokens=1024, hash_only=False, nan_entries=[(3, 6), (10, 0), (10, 9)]),
 ]
 
 
@@ -56,6 +59,8 @@ def run_case(c, ganq_mod, cfg_mod, NamedModule):
     g.L = torch.from_numpy(inp["L"])
     g.Xxt_damped = torch.from_numpy(inp["H"])
     Hinv = torch.diag(torch.from_numpy(inp["hinv_diag"]))
+    for (r, e) in c.get("nan_entries", []):
+        inp["T0"][r, e] = np.nan
     T0 = torch.from_numpy(inp["T0"])
 
     Qs = np.zeros((K, m, n), dtype=np.uint8)
@@ -83,11 +88,22 @@ def run_case(c, ganq_mod, cfg_mod, NamedModule):
 
     ganq_mod.GANQ._initialize_codebook_kmeans = lambda self, *a, **k: T0.clone()
     torch.argmin, torch.linalg.lstsq, ganq_mod.quad_loss_2 = argmin_wrap, lstsq_wrap, loss_wrap
+    loop_error = None
     try:
         Wq, Losses, _, _ = g._perform_quantization_loop(torch.from_numpy(inp["W"]).clone(), Hinv, 128)
+    except Exception as e:  # NaN case: LAPACK may refuse the NaN system after the S-solve was captured
+        if not c.get("nan_entries"):
+            raise
+        loop_error = e
     finally:
         ganq_mod.GANQ._initialize_codebook_kmeans = real_init
         torch.argmin, torch.linalg.lstsq, ganq_mod.quad_loss_2 = real_argmin, real_lstsq, real_loss
+    if c.get("nan_entries"):
+        assert rec["step"] >= n, loop_error
+        out = dict(m=m, n=n, bits=c["bits"], K=K, seed=c["seed"], tokens=c["tokens"], hash_only=False, nan_case=True,
+                   T0=inp["T0"], nan_entries=np.array(c["nan_entries"]), Q_first=Qs[0], sha_Q=np.array([exact_inputs.sha(Qs[0])]))
+        out.update({"sha_" + k: v for k, v in exact_inputs.hashes(inp).items()})
+        return out
     assert rec["step"] == K * n and len(rec["lstsq"]) == K and len(rec["loss"]) == K
     Ts = np.stack([inp["T0"]] + [s.mT.squeeze(-2).numpy() for s in rec["lstsq"]]).astype(np.float32)
     dists = np.array(rec["loss"], dtype=np.float64)
@@ -118,7 +134,7 @@ def main():
         out = run_case(c, ganq_mod, cfg_mod, NamedModule)
         path = os.path.join(OUT, c["name"] + ".npz")
         np.savez_compressed(path, **out)
-        print(f"{c['name']}: dists={out['dists']} -> {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
+        print(f"{c['name']}: dists={out.get('dists')} -> {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
 
 
 if __name__ == "__main__":
