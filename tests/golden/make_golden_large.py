@@ -40,6 +40,10 @@ CASES = [
     dict(name="l128x2048_b4_k10", m=128, n=2048, bits=4, K=10, seed=202, tokens=4096, hash_only=False),
     dict(name="l256x512_b2_k3", m=256, n=512, bits=2, K=3, seed=204, tokens=2048, hash_only=False),
     dict(name="h4096x4096_b4_k2", m=4096, n=4096, bits=4, K=2, seed=203, tokens=8192, hash_only=True),
+    # the module shapes of opt-125m (BASELINE.json configs[0] / [1]: fc1, fc2, attention projections), all K = 10 iterations
+    dict(name="h3072x768_b4_k10", m=3072, n=768, bits=4, K=10, seed=206, tokens=2048, hash_only=True),
+    dict(name="h768x3072_b4_k10", m=768, n=3072, bits=4, K=10, seed=207, tokens=4096, hash_only=True),
+    dict(name="h768x768_b4_k10", m=768, n=768, bits=4, K=10, seed=208, tokens=2048, hash_only=True),
     # torch.argmin's NaN semantics in the S-solve (ganq.py:547): two codebook entries are NaN; only the S-solve of the one
     # iteration is captured (what lstsq / the loss make of NaN inputs is not part of the contract: gptq.py:328-330 raises)
     dict(name="nan48x256_b4_k1", m=48, n=256, bits=4, K=1, seed=205, tokens=1024, hash_only=False, nan_entries=[(3, 6), (10, 0), (10, 9)]),

@@ -36,7 +36,7 @@ def case(name):
 
 def test_large_cases_present():
     assert {"l128x2048_b4_k3", "l128x2048_b3_k3", "l128x2048_b4_k10", "l256x512_b2_k3", "h4096x4096_b4_k2",
-            "nan48x256_b4_k1"} <= set(LARGE)
+            "h3072x768_b4_k10", "h768x3072_b4_k10", "h768x768_b4_k10", "nan48x256_b4_k1"} <= set(LARGE)
 
 
 # ------------------------------------------------------------------------------------------ CPU oracle
@@ -67,15 +67,20 @@ def test_oracle_vs_reference_large(name):
     assert abs(float(Lo.astype(np.float64).sum()) - float(fx["losses_sum"])) <= 1e-5 * float(fx["losses_sum"])
 
 
-def test_oracle_vs_reference_4096_hash_sampled_rows():
-    """CPU: 192 of the 4096 rows (rows are independent in the S-solve); the whole layer is the GPU test's"""
+@pytest.mark.parametrize("name", [n for n in LARGE if n.startswith("h")])
+def test_oracle_vs_reference_hash_cases_sampled_rows(name):
+    """CPU: up to 192 rows of the hash-only cases -- the 4096 x 4096 layer and the three module shapes of opt-125m with all
+    K = 10 iterations (rows are independent in the S-solve and the T-update); the whole layers are the GPU test's"""
     from oracle import c_oracle
 
-    fx, inp = case("h4096x4096_b4_k2")
-    rows = np.r_[0:64, 2000:2064, 4032:4096]
+    fx, inp = case(name)
+    m, V = int(fx["m"]), 2 ** int(fx["bits"])
+    rows = np.unique(np.r_[0:64, m // 2:m // 2 + 64, m - 64:m])
+    WH = c_oracle.matmul(inp["W"][rows], inp["H"])
     for k in range(int(fx["K"])):
         Q = c_oracle.solve_s(inp["W"][rows], inp["L"], fx["T"][k][rows])
-        assert np.array_equal(exact_inputs.row_digest(Q), fx["Q_row_digest"][k][rows])
+        assert np.array_equal(exact_inputs.row_digest(Q), fx["Q_row_digest"][k][rows]), f"{name} iteration {k}"
+        assert rel_fro(c_oracle.update_t(WH, inp["H"], Q, V), fx["T"][k + 1][rows]) < TOL_T
 
 
 # ------------------------------------------------------------------------------------------ HIP path
