@@ -65,6 +65,11 @@ enum Opt : int {
     OPT_LUT_GEMM_RM,
     OPT_LUT_GEMM_PIPE,
     OPT_PREP_OVERLAP,
+    OPT_SOLVE_DUO,
+    OPT_SOLVE_DUO_XA,
+    OPT_SOLVE_DUO_XB,
+    OPT_SOLVE_DUO_XMIN,
+    OPT_SOLVE_DUO_CMIN,
     OPT_COUNT
 };
 long long opt_get(int id);

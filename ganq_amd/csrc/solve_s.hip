@@ -14,6 +14,8 @@
 //       triangle of L read from LDS.
 //   Err (= W - T[Q]) is kept in a per-tile transposed scratch ErrT[tile][col][16 rows] so that the
 //   A operand of (G) is one coalesced 256 B read.
+#include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -340,6 +342,7 @@ __device__ __forceinline__ void panel_all(PanelState& st, const float4 (*Ld)[16]
 //   in descending order -- only who computes when has changed.  G also stages the next panel's triangle of L and
 //   its diagonal (double-buffered), P prefetches its next W columns.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4raw __attribute__((__vector_size__(16)));  // what the 16-byte buffer builtins carry
 
 #ifndef GANQ_MFMA_INPLACE
 #define GANQ_MFMA_INPLACE 1  // measured: 4096 x 4096 1.065 -> 1.039 ms, 2048 x 8192 2.91 -> 2.74 ms
@@ -517,8 +520,11 @@ __host__ __device__ __forceinline__ int64_t lr_block(int ct, int p, int NT, int 
 #endif
 
 __global__ __launch_bounds__(64) void l_pack_kernel(const float* __restrict__ L, int64_t ldl, int n, int NT, bool kasc,
-                                                    float* __restrict__ Lr) {
+                                                    float* __restrict__ Lr, uint32_t* __restrict__ ctrl, int ctrl_words) {
     const int ct = blockIdx.x, p = blockIdx.y;
+    if (ct == 0 && p == 0) {  // the ticket counter and the flags of the helper workgroups start clean with every layer
+        for (int i = threadIdx.x; i < ctrl_words; i += 64) ctrl[i] = 0u;
+    }
     if (p <= ct / SKR) return;  // only source panels strictly right of the tile's panel are ever read
     const int lane = threadIdx.x, c16 = lane & 15, ksub = lane >> 4;
     const int kslot = kasc ? (3 - ksub) : ksub;
@@ -541,13 +547,44 @@ __global__ __launch_bounds__(64) void l_pack_kernel(const float* __restrict__ L,
 //   registers) and publish R for panel b.  The chain of an output is still ONE accumulator running over the columns
 //   in descending order -- only who computes when has changed.  G also stages the next panel's triangle of L and
 //   its diagonal (double-buffered), P prefetches its next W columns.
+// ---- helper workgroups ("duo" launches) ---------------------------------------------------------------------------------
+// A tile's solve is a latency chain on ONE CU: its column steps and its residual chain share the SIMDs' issue slots and add up
+// (see DESIGN "Where the S-solve stands").  When the launch has at most half as many active tiles as the chip has CUs -- layers
+// of up to 2048 rows, the late iterations of taller ones (converged rows are skipped), row shards of a multi-GPU run -- every
+// tile gets a second workgroup on another CU that computes the FAR part of each panel's chain: the chain of panel b runs over
+// the source panels nb-1, nb-2, .., b+2 in this order; the helper takes the first h of them (they were solved long ago), hands
+// the 16 x 64 accumulators over through memory, and the tile's own chain waves continue with the x nearest panels and the
+// panel just solved.  Same MFMAs in the same order on the same accumulator values: bit-identical to the single-workgroup solve.
+//   main -> helper: every packed Err block goes to the tile's scratch with agent-scope stores, then `solved` = step (one flag
+//                   per tile, written by one lane after the step's barrier, i.e. after every wave's stores were acknowledged);
+//   helper -> main: accumulators to Facc[tile][step][wave] with agent-scope stores, then `ready[wave]` = step.
+// Flags carry a per-launch tag, so a stale flag of an earlier launch never matches; l_pack_kernel zeroes them once per layer.
+// Roles come from a ticket drawn at start, not from blockIdx: within 16 consecutive tickets the first 8 are tiles, the next 8
+// their helpers -- whatever set of workgroups is resident, all but at most 8 tiles have their helper resident too, and those
+// finish without waiting for anybody, so a helper that starts late only delays.  The tile never depends on it either: a chain
+// wave that waits longer than DUO_TIMEOUT for accumulators computes the whole chain itself from then on (same bits).
+constexpr int DUO_MAX_TILES = 128;            // tiles with a helper (scratch is sized for them)
+constexpr int DUO_CTRL_WORDS = 1 + DUO_MAX_TILES * 5;  // ticket, then {solved, ready[4]} per tile
+constexpr unsigned long long DUO_TIMEOUT = 20ull * 1000 * 1000;  // s_memtime ticks (0.2 s at 100 MHz)
+// number of source panels the tile's own waves keep, of the c = s - 1 panels of step s's chain (the nearest ones);
+// pol = xa | xb << 8 | xmin << 16 | cmin << 24:  x = max(xmin, xa c / 64 - xb) from c >= cmin on, everything below
+__host__ __device__ __forceinline__ int duo_near(int c, int pol) {
+    const int xa = pol & 255, xb = (pol >> 8) & 255, xmin = (pol >> 16) & 255, cmin = (pol >> 24) & 127;
+    if (pol == 0 || c < cmin) return c;
+    int x = ((xa * c) >> 6) - xb;
+    x = x > xmin ? x : xmin;
+    return x < c ? x : c;
+}
+
 template <bool KASC>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __restrict__ W, const float* __restrict__ L,
                                                       int64_t ldl, const float* __restrict__ Lr, int NT,
                                                       const float* __restrict__ T, int m, int n, int V,
                                                       uint8_t* __restrict__ Q, float* __restrict__ ErrOut,
                                                       float* __restrict__ ErrT, int pbase, const int* __restrict__ rowlist,
-                                                      const int* __restrict__ nactive, int opt_fast) {
+                                                      const int* __restrict__ nactive, int opt_fast,
+                                                      uint32_t* __restrict__ ctrl, float* __restrict__ Facc,
+                                                      float* __restrict__ ErrH, uint32_t tag, int duo_pol, int ncu) {
     __shared__ float4 Ld[SPLIT ? 1 : 2][SPLIT ? 1 : SB][16];  // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
     __shared__ __align__(16) float Ld4[SPLIT ? 2 * SB * SB : 4];  // split layout: [buf][jj][sub][k] <-> L[j0+jj][j0 + sub + 4k]
     __shared__ float Fs[SPLIT ? 3 : 1][SPLIT ? 16 : 1][16];    // split layout: sorted codebook, lo, hi of the 16 rows (set-up -> P wave)
@@ -568,6 +605,33 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // rowlist / nactive (device, may be null): solve only these rows (the loop driver passes the rows that have not
+    // reached their fixed point yet); tile t then holds rows rowlist[16 t .. 16 t + 15]
+    const int nact = nactive ? *nactive : m;
+    int tile = blockIdx.x;
+    bool duo = false, helper = false;
+    if constexpr (!SPLIT) {
+        if (duo_pol != 0) {  // roles by ticket (see above)
+            __shared__ uint32_t s_tk;
+            if (tid == 0) {
+                const uint32_t t = __hip_atomic_fetch_add(&ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the last one to draw: everybody has, the counter is clean for the next launch
+                if (t == gridDim.x - 1) __hip_atomic_store(&ctrl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_tk = t;
+            }
+            __syncthreads();
+            const int tk = (int)s_tk;
+            const int A = (min(nact, m) + SR - 1) / SR;  // active tiles
+            duo = A <= DUO_MAX_TILES && 16 * ((A + 7) >> 3) <= min((int)gridDim.x, ncu);
+            if (duo) {
+                tile = (tk >> 4) * 8 + (tk & 7);
+                helper = (tk & 8) != 0;
+            } else {
+                tile = tk;
+            }
+        }
+    }
+    if (tile * SR >= nact) return;  // uniform for the workgroup, before any other barrier
     bool roleG;
     int gw;  // index of the wave inside its role
     if constexpr (SPLIT) {
@@ -614,18 +678,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     }
     const int gtid = gw * 64 + lane;  // thread index inside the role
     if (SOLVE_PF && wv == 8) {
-        if (!(opt_fast & 2)) return;  // not asked for: gone before the first barrier
+        if (!(opt_fast & 2) || helper) return;  // not asked for: gone before the first barrier
         // Prefetch wave.  Every workgroup walks the packed L in the same order at about the same pace, and every block is
         // read exactly once per workgroup: the first of the 32 workgroups behind one L2 to ask for a block waits for HBM
         // (the 67 MB do not stay in the Infinity Cache between launches), and the others, in step with it, wait along --
         // the chain ran at the latency of that miss, not at the rate of the matrix cores.  This wave touches, one step
         // ahead, the lines the chain waves of its XCD will read in the next step (a tile's blocks are contiguous in the
         // tile-major layout; the workgroups of an XCD share the lines out among themselves), and does nothing else.
-        const int nact_ = nactive ? *nactive : m;
-        if ((int)blockIdx.x * SR >= nact_) return;
         const int nb_ = (n + SB - 1) / SB;
-        const int nwg = (min(nact_, m) + SR - 1) / SR;            // workgroups that run
-        const int xi = (int)blockIdx.x >> 3, nx = (nwg + 7) >> 3;  // this workgroup among those of its XCD (blockIdx % 8)
+        const int nwg = (min(nact, m) + SR - 1) / SR;   // tiles that run
+        const int xi = tile >> 3, nx = (nwg + 7) >> 3;  // this tile among those of its XCD (blockIdx % 8)
         float sink = 0.0f;
         for (int s_ = 0; s_ <= nb_; ++s_) {
             const int bn = nb_ - 2 - s_;  // the panel whose chain runs in the NEXT step
@@ -644,14 +706,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
         if (sink == 1.2345e-30f) ErrT[0] = sink;  // never true: keeps the loads
         return;
     }
-    const int tile = blockIdx.x;
+    if (helper && (!roleG || duo_pol < 0)) return;  // a helper workgroup is four chain waves (pol bit 31, tests: helpers that never answer)
     const int rsub = lane >> 4;
     const int c16 = lane & 15;
     const int prow_in_tile = 4 * gw + rsub;  // row handled by this 16-lane group in phase (P)
-    // rowlist / nactive (device, may be null): solve only these rows (the loop driver passes the rows that have not
-    // reached their fixed point yet); tile t then holds rows rowlist[16 t .. 16 t + 15]
-    const int nact = nactive ? *nactive : m;
-    if (tile * SR >= nact) return;  // uniform for the workgroup, before any barrier
     const int slot = tile * SR + prow_in_tile;
     const bool prow_ok = slot < nact;
     const int prow = rowlist ? rowlist[min(slot, nact - 1)] : min(slot, m - 1);
@@ -953,9 +1011,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                         const int col = c16 + 16 * k;
                         const float ev = (col < wd) ? st.e[k] : 0.0f;  // the (partial) top panel is zero beyond n
                         ErrPk[pk_idx[k]] = ev;
-                        // the block lives in LDS (panels >= pbase, never read back from memory) or in the global scratch
+                        // the block lives in LDS (panels >= pbase, never read back from memory) or in the global scratch; with a
+                        // helper workgroup every block also goes to the scratch, visible to the other CU
                         if (bP >= pbase) ErrL[(bP - pbase) * SBLK + pk_idx[k]] = ev;
-                        else errt[bP * SBLK + pk_idx[k]] = ev;
+                        if (duo) __hip_atomic_store(&errt[bP * SBLK + pk_idx[k]], ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else if (bP < pbase) errt[bP * SBLK + pk_idx[k]] = ev;
                         if (col < wd && prow_ok) {
                             Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
                             if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
@@ -970,8 +1030,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                     }
                 }
             GANQ_TRACE(0, s, 2);
+            if (duo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's Err stores are acknowledged
             __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
             GANQ_TRACE(0, s, 3);
+            // (the barrier waited for every wave's stores: the panel's block is in memory before the helper hears of it)
+            if (duo && tid == 0 && s >= 1) __hip_atomic_store(&ctrl[1 + 5 * tile], tag | (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
             GANQ_TRACE(0, s, 4);
         }
@@ -991,116 +1054,169 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     constexpr bool PRIME = GANQ_SOLVE_PRIME != 0 && GANQ_MFMA_INPLACE != 0;
     f32x4v ra[RING][SKR], rb[RING][SKR];
     bool primed = false;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    // shared by both roles (the P waves run a chain too when they assist, see below)
+    const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0xffffffff, 0x00020000);
+    // (a helper workgroup reads its own copy of the tile's Err blocks, see below)
+    float* __restrict__ errg = helper ? ErrH + (int64_t)tile * nb * SBLK : errt;
+    const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errg, 0, 0xffffffff, 0x00020000);
+    // zero records: every load through it is out of range and returns 0
+    const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0, 0x00020000);
+    const int voff = lane * 16;  // this lane's 16 bytes inside each quarter of a packed block
+    // One chain segment: source panels phi, phi-1, .., plo (descending), A from LDS (panels >= pbase) or from
+    // the global scratch.  One batch = one source panel = 16 MFMAs; operands are loaded two batches ahead into
+    // three rotating register sets; every load is unconditional and the loop runs whole rounds of three
+    // (batches past the end read B through rsrcZ: zeros leave the accumulator as it is), so that the waits
+    // in the steady state count exactly the loads still allowed in flight.
+    // a_in_lds: 1 = every A block of the segment is in LDS, 0 = none, 2 = decided per batch (split layout: ONE segment per
+    // step, so the ring is filled once -- each fill is a full memory round trip before the first MFMA)
+    auto chain = [&](auto a_in_lds, int phi, int plo, const int ct, bool have_head) {
+        constexpr bool ALDS = decltype(a_in_lds)::value == 1;
+        constexpr bool MIXED = decltype(a_in_lds)::value == 2;
+        const int nbat = phi - plo + 1;
+        if (nbat <= 0) return;
+        auto& a = ra;
+        auto& b = rb;
+        auto ld = [&](int bi, f32x4v (&aa)[SKR], f32x4v (&bb)[SKR]) {
+            const bool real = bi < nbat;
+            const int ps = phi - min(bi, nbat - 1);  // source panel of the batch
+            const uint32_t sB = (uint32_t)lr_block(ct, ps, NT, nb) * (uint32_t)SBLKB;
+            const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
+            const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * SBLK + lane * 4);
+#pragma unroll
+            for (int j = 0; j < SKR; ++j) {
+                bb[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * j, (int)sB, 0));
+                if (ALDS || (MIXED && ps >= pbase)) aa[j] = Al[j * 64];
+                else aa[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * j, ps * SBLKB, 0));
+            }
+        };
+        auto mm = [&](const f32x4v (&aa)[SKR], const f32x4v (&bb)[SKR]) {
+#pragma unroll
+            for (int g = SKG - 1; g >= 0; --g) {
+#if GANQ_MFMA_INPLACE
+                // accumulate IN PLACE: the register allocator otherwise moves the accumulator between registers along
+                // the chain, and a dependent MFMA whose destination differs from its SrcC loses the back-to-back path
+                mfma_inplace(acc, aa[g >> 2][g & 3], bb[g >> 2][g & 3]);
+#else
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g >> 2][g & 3], bb[g >> 2][g & 3], acc, 0, 0, 0);
+#endif
+            }
+        };
+        // GANQ_SOLVE_RING register sets in rotation: the operands of batch k + RING - 1 are requested while batch k is
+        // multiplied (B comes from L2 / the Infinity Cache: the deeper the ring, the more of that latency is covered)
+        if (!have_head) {  // wave-uniform
+#pragma unroll
+            for (int u = 0; u < RING - 1; ++u) ld(u, a[u], b[u]);
+        }
+        GANQ_PIN();
+        // one stage = the loads of a later batch spread between the 16 MFMAs of batch k
+        auto stage_sched = [&]() {
+#pragma unroll
+            for (int i = 0; i < SKR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (B)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (ALDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (A)
+                else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (A)
+            }
+        };
+#if GANQ_MFMA_INPLACE
+        // the MFMAs are inline assembly (see mm), which the scheduler leaves where it is written together with the loads
+        // around it: the interleaving is spelled out -- after every 4 MFMAs of batch k, one 16-byte piece of B and of A of
+        // batch k + RING - 1
+        auto mm_ld = [&](const f32x4v (&aa)[SKR], const f32x4v (&bb)[SKR], int bi, f32x4v (&an)[SKR], f32x4v (&bn)[SKR]) {
+            const bool real = bi < nbat;
+            const int ps = phi - min(bi, nbat - 1);
+            const uint32_t sB = (uint32_t)lr_block(ct, ps, NT, nb) * (uint32_t)SBLKB;
+            const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
+            const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * SBLK + lane * 4);
+            const bool a_lds = ALDS || (MIXED && ps >= pbase);  // wave-uniform
+#pragma unroll
+            for (int j = SKR - 1; j >= 0; --j) {
+#pragma unroll
+                for (int g = 4 * j + 3; g >= 4 * j; --g) mfma_inplace(acc, aa[g >> 2][g & 3], bb[g >> 2][g & 3]);
+                const int jl = SKR - 1 - j;
+                bn[jl] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * jl, (int)sB, 0));
+                if (a_lds) an[jl] = Al[jl * 64];
+                else an[jl] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * jl, ps * SBLKB, 0));
+            }
+        };
+        for (int bi = 0; bi < nbat; bi += RING) {  // whole rounds, no exits inside: a plain counted loop
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                mm_ld(a[u], b[u], bi + u + RING - 1, a[(u + RING - 1) % RING], b[(u + RING - 1) % RING]);
+                GANQ_PIN();
+            }
+        }
+        (void)mm;
+        (void)stage_sched;
+#else
+        for (int bi = 0; bi < nbat; bi += RING) {  // whole rounds, no exits inside: a plain counted loop
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                ld(bi + u + RING - 1, a[(u + RING - 1) % RING], b[(u + RING - 1) % RING]);
+                mm(a[u], b[u]);
+                stage_sched();
+                GANQ_PIN();
+            }
+        }
+#endif
+    };
+    // ---- helper workgroup: the far part of every panel's chain (see "duo" above) ---------------------------------------
+    if (helper) {
+        if constexpr (!SPLIT) {
+            const __amdgpu_buffer_rsrc_t rsrcM = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);  // the tile's blocks
+            const __amdgpu_buffer_rsrc_t rsrcF =
+                __builtin_amdgcn_make_buffer_rsrc(Facc + (int64_t)tile * (nb + 1) * SBLK, 0, 0xffffffff, 0x00020000);
+            const uint32_t* solved = ctrl + 1 + 5 * tile;
+            uint32_t* ready = ctrl + 1 + 5 * tile + 1 + gw;
+            int have = nb;  // lowest panel copied so far
+            for (int s = 1; s <= nb - 1; ++s) {
+                const int c = s - 1;
+                const int h = c - duo_near(c, duo_pol);  // source panels nb-1 .. nb-h are this workgroup's
+                if (h <= 0) continue;
+                const int need = nb - h;
+                if (need < have) {  // (uniform over the four waves)
+                    // panel p was solved in step nb - p: wait until the tile has announced step h
+                    if (lane == 0) {
+                        for (;;) {
+                            const uint32_t v = __hip_atomic_load(solved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)h) break;
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // copy the new blocks: 4 KB each, 16 bytes per thread; into LDS (panels >= pbase) or this workgroup's own
+                    // scratch (plain stores and loads from here on: one CU, one L1)
+                    for (int pp = have - 1; pp >= need; --pp) {
+                        const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcM, gtid * 16, pp * SBLKB, 16));
+                        if (pp >= pbase) *reinterpret_cast<f32x4v*>(ErrL + (pp - pbase) * SBLK + gtid * 4) = v;
+                        else *reinterpret_cast<f32x4v*>(errg + pp * SBLK + gtid * 4) = v;
+                    }
+                    have = need;
+                    __syncthreads();
+                }
+                acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                const int ct = SKR * (nb - 1 - s) + gw;  // this wave's 16-wide tile of panel bG = nb - 1 - s
+                const int plds = max(need, pbase);
+                chain(std::integral_constant<int, 1>{}, nb - 1, plds, ct, false);
+                chain(std::integral_constant<int, 0>{}, min(nb - 1, plds - 1), need, ct, false);
+#if GANQ_MFMA_INPLACE
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4raw, acc), rsrcF, voff + 1024 * gw, s * SBLKB, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged = visible to every CU
+                if (lane == 0) __hip_atomic_store(ready, tag | (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    bool duo_live = duo;  // (per chain wave) the helper's accumulators are still being waited for
     for (int s = 0; s <= nb; ++s) {
         const int bG = nb - 1 - s;  // panel whose residual is produced in this step (none at s = nb)
         GANQ_TRACE(1, s, 0);
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         f32x4v bpre[SKR];  // (G) packed L block (source panel bG+1, this wave's tile): the B operands of part 2
-        // shared by both roles (the P waves run a chain too when they assist, see below)
-        const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0xffffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);
-        // zero records: every load through it is out of range and returns 0
-        const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0, 0x00020000);
-        const int voff = lane * 16;  // this lane's 16 bytes inside each quarter of a packed block
-        // One chain segment: source panels phi, phi-1, .., plo (descending), A from LDS (panels >= pbase) or from
-        // the global scratch.  One batch = one source panel = 16 MFMAs; operands are loaded two batches ahead into
-        // three rotating register sets; every load is unconditional and the loop runs whole rounds of three
-        // (batches past the end read B through rsrcZ: zeros leave the accumulator as it is), so that the waits
-        // in the steady state count exactly the loads still allowed in flight.
-        // a_in_lds: 1 = every A block of the segment is in LDS, 0 = none, 2 = decided per batch (split layout: ONE segment per
-        // step, so the ring is filled once -- each fill is a full memory round trip before the first MFMA)
-        auto chain = [&](auto a_in_lds, int phi, int plo, const int ct, bool have_head) {
-            constexpr bool ALDS = decltype(a_in_lds)::value == 1;
-            constexpr bool MIXED = decltype(a_in_lds)::value == 2;
-            const int nbat = phi - plo + 1;
-            if (nbat <= 0) return;
-            auto& a = ra;
-            auto& b = rb;
-            auto ld = [&](int bi, f32x4v (&aa)[SKR], f32x4v (&bb)[SKR]) {
-                const bool real = bi < nbat;
-                const int ps = phi - min(bi, nbat - 1);  // source panel of the batch
-                const uint32_t sB = (uint32_t)lr_block(ct, ps, NT, nb) * (uint32_t)SBLKB;
-                const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
-                const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * SBLK + lane * 4);
-#pragma unroll
-                for (int j = 0; j < SKR; ++j) {
-                    bb[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * j, (int)sB, 0));
-                    if (ALDS || (MIXED && ps >= pbase)) aa[j] = Al[j * 64];
-                    else aa[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * j, ps * SBLKB, 0));
-                }
-            };
-            auto mm = [&](const f32x4v (&aa)[SKR], const f32x4v (&bb)[SKR]) {
-#pragma unroll
-                for (int g = SKG - 1; g >= 0; --g) {
-#if GANQ_MFMA_INPLACE
-                    // accumulate IN PLACE: the register allocator otherwise moves the accumulator between registers along
-                    // the chain, and a dependent MFMA whose destination differs from its SrcC loses the back-to-back path
-                    mfma_inplace(acc, aa[g >> 2][g & 3], bb[g >> 2][g & 3]);
-#else
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g >> 2][g & 3], bb[g >> 2][g & 3], acc, 0, 0, 0);
-#endif
-                }
-            };
-            // GANQ_SOLVE_RING register sets in rotation: the operands of batch k + RING - 1 are requested while batch k is
-            // multiplied (B comes from L2 / the Infinity Cache: the deeper the ring, the more of that latency is covered)
-            if (!have_head) {  // wave-uniform
-#pragma unroll
-                for (int u = 0; u < RING - 1; ++u) ld(u, a[u], b[u]);
-            }
-            GANQ_PIN();
-            // one stage = the loads of a later batch spread between the 16 MFMAs of batch k
-            auto stage_sched = [&]() {
-#pragma unroll
-                for (int i = 0; i < SKR; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);             // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (B)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    if (ALDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (A)
-                    else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (A)
-                }
-            };
-#if GANQ_MFMA_INPLACE
-            // the MFMAs are inline assembly (see mm), which the scheduler leaves where it is written together with the loads
-            // around it: the interleaving is spelled out -- after every 4 MFMAs of batch k, one 16-byte piece of B and of A of
-            // batch k + RING - 1
-            auto mm_ld = [&](const f32x4v (&aa)[SKR], const f32x4v (&bb)[SKR], int bi, f32x4v (&an)[SKR], f32x4v (&bn)[SKR]) {
-                const bool real = bi < nbat;
-                const int ps = phi - min(bi, nbat - 1);
-                const uint32_t sB = (uint32_t)lr_block(ct, ps, NT, nb) * (uint32_t)SBLKB;
-                const __amdgpu_buffer_rsrc_t rsB = real ? rsrcL : rsrcZ;
-                const f32x4v* Al = reinterpret_cast<const f32x4v*>(ErrL + (ps - pbase) * SBLK + lane * 4);
-                const bool a_lds = ALDS || (MIXED && ps >= pbase);  // wave-uniform
-#pragma unroll
-                for (int j = SKR - 1; j >= 0; --j) {
-#pragma unroll
-                    for (int g = 4 * j + 3; g >= 4 * j; --g) mfma_inplace(acc, aa[g >> 2][g & 3], bb[g >> 2][g & 3]);
-                    const int jl = SKR - 1 - j;
-                    bn[jl] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 1024 * jl, (int)sB, 0));
-                    if (a_lds) an[jl] = Al[jl * 64];
-                    else an[jl] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voff + 1024 * jl, ps * SBLKB, 0));
-                }
-            };
-            for (int bi = 0; bi < nbat; bi += RING) {  // whole rounds, no exits inside: a plain counted loop
-#pragma unroll
-                for (int u = 0; u < RING; ++u) {
-                    mm_ld(a[u], b[u], bi + u + RING - 1, a[(u + RING - 1) % RING], b[(u + RING - 1) % RING]);
-                    GANQ_PIN();
-                }
-            }
-            (void)mm;
-            (void)stage_sched;
-#else
-            for (int bi = 0; bi < nbat; bi += RING) {  // whole rounds, no exits inside: a plain counted loop
-#pragma unroll
-                for (int u = 0; u < RING; ++u) {
-                    ld(bi + u + RING - 1, a[(u + RING - 1) % RING], b[(u + RING - 1) % RING]);
-                    mm(a[u], b[u]);
-                    stage_sched();
-                    GANQ_PIN();
-                }
-            }
-#endif
-        };
         if (bG >= 0) {
             // ---- (G) part 1: the panels right of panel bG+1, descending --------------------------------------
             const int j0 = bG * SB;
@@ -1130,12 +1246,44 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             }
             const int plds = max(bG + 2, pbase);  // lowest source panel of this chain whose Err block lives in LDS
 #ifndef GANQ_SOLVE_NO_G  // timing experiment: results are meaningless without the residual chain
+            // with a helper workgroup: the first h source panels of the chain are its work, the accumulators come from memory
+            int top = nb - 1;
+            if constexpr (!SPLIT) {
+                if (duo_live) {
+                    const int c = s - 1, h = c - duo_near(c, duo_pol);
+                    if (h > 0) {
+                        int ok = 0;
+                        if (lane == 0) {
+                            const uint32_t* ready = ctrl + 1 + 5 * tile + 1 + gw;
+                            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                            for (;;) {
+                                const uint32_t v = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)s) {
+                                    ok = 1;
+                                    break;
+                                }
+                                if (__builtin_amdgcn_s_memtime() - t0 > DUO_TIMEOUT) break;
+                                __builtin_amdgcn_s_sleep(4);
+                            }
+                        }
+                        ok = __builtin_amdgcn_readfirstlane(ok);
+                        if (ok) {
+                            const __amdgpu_buffer_rsrc_t rsrcF =
+                                __builtin_amdgcn_make_buffer_rsrc(Facc + (int64_t)tile * (nb + 1) * SBLK, 0, 0xffffffff, 0x00020000);
+                            acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcF, voff + 1024 * gw, s * SBLKB, 16));
+                            top = nb - 1 - h;
+                        } else {
+                            duo_live = false;  // no helper in sight: this wave computes its chains alone from here on
+                        }
+                    }
+                }
+            }
             if constexpr (false) {  // ONE mixed segment per step (A source decided per batch): measured slower, 23.5 vs 17.9 us for
                 (void)plds;         // the last chains -- the per-batch branch costs the ring its load / MFMA interleave
                 chain(std::integral_constant<int, 2>{}, nb - 1, bG + 2, ct, false);
             } else {
-                chain(std::integral_constant<int, 1>{}, nb - 1, plds, ct, PRIME && primed);
-                chain(std::integral_constant<int, 0>{}, min(nb - 1, plds - 1), bG + 2, ct, false);
+                chain(std::integral_constant<int, 1>{}, top, plds, ct, PRIME && primed);
+                chain(std::integral_constant<int, 0>{}, min(top, plds - 1), bG + 2, ct, false);
             }
 #if GANQ_MFMA_INPLACE
             // (inline assembly is invisible to the hazard recogniser: let the last MFMA retire before acc is read again)
@@ -1211,7 +1359,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
 
 struct SolveLayout {
     int nb, NT;
-    size_t errt_bytes, lr_bytes, total;
+    size_t errt_bytes, lr_bytes, facc_bytes, errh_bytes, ctrl_bytes, total;
 };
 static SolveLayout solve_layout(int64_t m, int64_t n) {
     SolveLayout lo;
@@ -1220,7 +1368,12 @@ static SolveLayout solve_layout(int64_t m, int64_t n) {
     const int64_t tiles = (m + SR - 1) / SR;
     lo.errt_bytes = align_up((size_t)tiles * (size_t)lo.nb * SBLKB, 256);
     lo.lr_bytes = align_up((size_t)lo.nb * (size_t)lo.NT * SBLKB, 256);
-    lo.total = lo.errt_bytes + lo.lr_bytes;
+    // helper workgroups (SB == 64 only): accumulators per (tile, step), the helpers' own copy of the Err blocks, flags
+    const size_t dt = SPLIT ? 0 : (size_t)std::min<int64_t>(tiles, DUO_MAX_TILES);
+    lo.facc_bytes = align_up(dt * (size_t)(lo.nb + 1) * SBLKB, 256);
+    lo.errh_bytes = align_up(dt * (size_t)lo.nb * SBLKB, 256);
+    lo.ctrl_bytes = align_up((size_t)DUO_CTRL_WORDS * sizeof(uint32_t), 256);
+    lo.total = lo.errt_bytes + lo.lr_bytes + lo.facc_bytes + lo.errh_bytes + lo.ctrl_bytes;
     return lo;
 }
 
@@ -1241,8 +1394,9 @@ int solve_s_pack_l(const float* L, int64_t ldl, int64_t m, int64_t n, void* work
     int rc = ganq_hip_selftest(stream);
     if (rc) return rc;
     ProfScope prof(KID_T_PREP, stream);  // per-layer preparation, reported with the T-update's
+    uint32_t* ctrl = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + lo.errt_bytes + lo.lr_bytes + lo.facc_bytes + lo.errh_bytes);
     hipLaunchKernelGGL(l_pack_kernel, dim3((unsigned)lo.NT, (unsigned)lo.nb), dim3(64), 0, stream, L, ldl, (int)n, lo.NT,
-                       mfma_k_ascending(), Lr);
+                       mfma_k_ascending(), Lr, ctrl, DUO_CTRL_WORDS);
     GANQ_LAUNCH_CHECK();
     return 0;
 }
@@ -1277,17 +1431,40 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
         if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(solve_s_kernel<false>), smem);
         if (rc) return rc;
     }
+    // helper workgroups (see "duo" at the kernel): asked for when the launch could have at most half as many active tiles as
+    // the chip has CUs and the chains are long enough to matter; the kernel decides by the rows really active
+    char* wsb = static_cast<char*>(workspace);
+    float* facc = reinterpret_cast<float*>(wsb + lo.errt_bytes + lo.lr_bytes);
+    float* errh = reinterpret_cast<float*>(wsb + lo.errt_bytes + lo.lr_bytes + lo.facc_bytes);
+    uint32_t* ctrl = reinterpret_cast<uint32_t*>(wsb + lo.errt_bytes + lo.lr_bytes + lo.facc_bytes + lo.errh_bytes);
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v;
+    }();
+    int duo_pol = 0, grid = tiles;
+    if (!SPLIT && opt_get(OPT_SOLVE_DUO) != 0 && ncu >= 16 && lo.nb <= 1000) {
+        const int xa = (int)opt_get(OPT_SOLVE_DUO_XA), xb = (int)opt_get(OPT_SOLVE_DUO_XB), xmin = (int)opt_get(OPT_SOLVE_DUO_XMIN),
+                  cmin = (int)opt_get(OPT_SOLVE_DUO_CMIN);
+        const int pol = (xa & 255) | ((xb & 255) << 8) | ((std::max(xmin, 1) & 255) << 16) | ((std::max(cmin, 1) & 127) << 24);
+        if (lo.nb - 2 >= std::max(cmin, 1)) {  // some chain is long enough to be shared
+            duo_pol = opt_get(OPT_SOLVE_DUO) == 2 ? (int)((unsigned)pol | 0x80000000u) : pol;  // 2 (tests): mute helpers, see the kernel
+            grid = std::max(tiles, std::min(16 * ((tiles + 7) / 8), ncu / 16 * 16));
+        }
+    }
+    static std::atomic<uint32_t> epoch{0};
+    const uint32_t tag = ((epoch.fetch_add(1) + 1u) & 0x3fffffu) << 10;  // per-launch tag of the flags (never 0)
     ProfScope prof(KID_SOLVE_S, stream);
     int fast = opt_get(OPT_SOLVE_VARIANT) == 1 ? 0 : 1;  // GANQ_SOLVE_VARIANT=1: reduction path only (A/B, tests)
     // bit 1: the prefetch wave.  It pays where one workgroup per CU walks a long L (measured: 2048 x 8192 3.26 -> 2.91 ms;
     // 4096 x 4096 unchanged; with several workgroups per CU, 14336 x 4096, it costs 5 %: they cover each other's misses)
     if (SOLVE_PF && tiles <= 256 && n > 4096) fast |= 2;
     if (mfma_k_ascending()) {
-        hipLaunchKernelGGL(solve_s_kernel<true>, dim3(tiles), dim3(SOLVE_THREADS), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
-                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast);
+        hipLaunchKernelGGL(solve_s_kernel<true>, dim3(grid), dim3(SOLVE_THREADS), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
+                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast, ctrl, facc, errh, tag, duo_pol, ncu);
     } else {
-        hipLaunchKernelGGL(solve_s_kernel<false>, dim3(tiles), dim3(SOLVE_THREADS), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
-                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast);
+        hipLaunchKernelGGL(solve_s_kernel<false>, dim3(grid), dim3(SOLVE_THREADS), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
+                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast, ctrl, facc, errh, tag, duo_pol, ncu);
     }
     GANQ_LAUNCH_CHECK();
     return 0;

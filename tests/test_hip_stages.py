@@ -151,6 +151,33 @@ def test_solve_s_threshold_path_adversarial_codebooks(hip, oracle, case, lib_opt
         assert (outs[0][:, 3] == 0).all() and (outs[0][:, 1] == 5).all()
 
 
+@pytest.mark.parametrize("m,n,V,seed", [(300, 1536, 16, 31), (2048, 2048, 16, 32), (37, 4100, 8, 33), (130, 700, 16, 34)])
+def test_solve_s_helper_workgroups_bit_identical(hip, oracle, m, n, V, seed, lib_options):
+    """Launches with at most half as many tiles as CUs give every tile a helper workgroup that computes the far part of each
+    residual chain on another CU and hands the accumulators over through memory (solve_s.hip, "duo").  Same MFMAs in the same
+    order: the indices AND the errors must be the bits of the single-workgroup solve, whatever the split policy -- and also
+    when the helpers never answer (GANQ_SOLVE_DUO=2: the tile's chain waves time out once and compute everything themselves)."""
+    W, H, L, T0 = synth(m, n, V, seed, corr=0.1)
+    if seed == 31:  # rows with a NaN codebook entry next to ordinary rows of the same tile (MFMA rows are independent)
+        T0[5, 3] = np.nan
+        T0[170, 0] = np.nan
+    Wd, Ld, Td = dev(W), dev(L), dev(T0)
+    lib_options(GANQ_SOLVE_DUO=0)
+    Q0, E0 = hip.solve_s(Wd, Ld, Td, want_err=True)
+    runs = [dict(GANQ_SOLVE_DUO=1), dict(GANQ_SOLVE_DUO=2),
+            dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_DUO_XA=0, GANQ_SOLVE_DUO_XB=0, GANQ_SOLVE_DUO_XMIN=1, GANQ_SOLVE_DUO_CMIN=1),   # all but one panel far
+            dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_DUO_XA=60, GANQ_SOLVE_DUO_XB=0, GANQ_SOLVE_DUO_XMIN=1, GANQ_SOLVE_DUO_CMIN=3),  # nearly all near
+            dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_DUO_XA=20, GANQ_SOLVE_DUO_XB=5, GANQ_SOLVE_DUO_XMIN=3, GANQ_SOLVE_DUO_CMIN=12)]
+    for opts in runs:
+        lib_options(**opts)
+        for _ in range(2):  # twice: the flags of the first launch must not satisfy the second
+            Q1, E1 = hip.solve_s(Wd, Ld, Td, want_err=True)
+            assert torch.equal(Q0, Q1), f"{opts}: {(Q0 != Q1).sum().item()} indices differ from the single-workgroup solve"
+            assert torch.equal(E0.view(torch.int32), E1.view(torch.int32)), f"{opts}: errors differ"
+    rows = np.unique(np.r_[0:min(m, 24), 160:min(m, 176), m - 8:m])
+    assert np.array_equal(Q0.cpu().numpy()[rows], oracle.solve_s(W[rows], L, T0[rows]))
+
+
 def test_solve_s_strided_L_and_empty(hip, oracle):
     W, H, L, T0 = synth(16, 96, 16, 10)
     Lbig = torch.zeros(96, 160, device="cuda")
