@@ -46,7 +46,7 @@ const OptDesc kOpts[OPT_COUNT] = {
                                    // 4096^2 14.13 -> 14.28 ms, 1024x4096 9.90 -> 9.87, 768x3072 6.36 -> 6.29: the S-solve holds 130 KB of
                                    // every CU's LDS, what runs beside it runs on its issue slots; off)
     {"GANQ_SOLVE_DUO", 1},         // S-solve: 0 = never launch helper workgroups (solve_s.hip, "duo"); 2 (tests) = helpers that never answer
-    {"GANQ_SOLVE_DUO_XA", 38},     // ... source panels the tile keeps of a chain of c: max(XMIN, XA c / 64 - XB) from c >= CMIN on
+    {"GANQ_SOLVE_DUO_XA", 44},     // ... source panels the tile keeps of a chain of c: max(XMIN, XA c / 64 - XB) from c >= CMIN on
     {"GANQ_SOLVE_DUO_XB", 12},
     {"GANQ_SOLVE_DUO_XMIN", 2},
     {"GANQ_SOLVE_DUO_CMIN", 8},

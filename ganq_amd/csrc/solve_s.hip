@@ -559,12 +559,12 @@ __global__ __launch_bounds__(64) void l_pack_kernel(const float* __restrict__ L,
 //                   per tile, written by one lane after the step's barrier, i.e. after every wave's stores were acknowledged);
 //   helper -> main: accumulators to Facc[tile][step][wave] with agent-scope stores, then `ready[wave]` = step.
 // Flags carry a per-launch tag, so a stale flag of an earlier launch never matches; l_pack_kernel zeroes them once per layer.
-// Roles come from a ticket drawn at start, not from blockIdx: within 16 consecutive tickets the first 8 are tiles, the next 8
-// their helpers -- whatever set of workgroups is resident, all but at most 8 tiles have their helper resident too, and those
-// finish without waiting for anybody, so a helper that starts late only delays.  The tile never depends on it either: a chain
+// Roles come from a ticket drawn at start, not from blockIdx (one counter per blockIdx mod 8): even tickets of a class are tiles,
+// the next odd one its helper -- whatever set of workgroups is resident, all but at most 8 tiles have their helper resident too,
+// and those finish without waiting for anybody, so a helper that starts late only delays.  The tile never depends on it either: a chain
 // wave that waits longer than DUO_TIMEOUT for accumulators computes the whole chain itself from then on (same bits).
 constexpr int DUO_MAX_TILES = 128;            // tiles with a helper (scratch is sized for them)
-constexpr int DUO_CTRL_WORDS = 1 + DUO_MAX_TILES * 5;  // ticket, then {solved, ready[4]} per tile
+constexpr int DUO_CTRL_WORDS = 8 + DUO_MAX_TILES * 5;  // 8 ticket counters, then {solved, ready[4]} per tile
 constexpr unsigned long long DUO_TIMEOUT = 20ull * 1000 * 1000;  // s_memtime ticks (0.2 s at 100 MHz)
 // number of source panels the tile's own waves keep, of the c = s - 1 panels of step s's chain (the nearest ones);
 // pol = xa | xb << 8 | xmin << 16 | cmin << 24:  x = max(xmin, xa c / 64 - xb) from c >= cmin on, everything below
@@ -611,23 +611,25 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     int tile = blockIdx.x;
     bool duo = false, helper = false;
     if constexpr (!SPLIT) {
-        if (duo_pol != 0) {  // roles by ticket (see above)
-            __shared__ uint32_t s_tk;
-            if (tid == 0) {
-                const uint32_t t = __hip_atomic_fetch_add(&ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // the last one to draw: everybody has, the counter is clean for the next launch
-                if (t == gridDim.x - 1) __hip_atomic_store(&ctrl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_tk = t;
-            }
-            __syncthreads();
-            const int tk = (int)s_tk;
+        if (duo_pol != 0) {
             const int A = (min(nact, m) + SR - 1) / SR;  // active tiles
             duo = A <= DUO_MAX_TILES && 16 * ((A + 7) >> 3) <= min((int)gridDim.x, ncu);
-            if (duo) {
-                tile = (tk >> 4) * 8 + (tk & 7);
-                helper = (tk & 8) != 0;
-            } else {
-                tile = tk;
+            if (duo) {  // roles by ticket (see above); a launch without helpers keeps tile = blockIdx and draws nothing
+                // one counter per residue class of blockIdx mod 8 (an XCD, when workgroups are dealt round-robin): 256 draws on one
+                // address serialise for tens of microseconds, and a pair drawn from one class shares an L2
+                __shared__ uint32_t s_tk;
+                const int cls = (int)(blockIdx.x & 7u);
+                if (tid == 0) {
+                    const uint32_t t = __hip_atomic_fetch_add(&ctrl[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t in_class = (gridDim.x - (uint32_t)cls + 7u) >> 3;
+                    // the last one of the class to draw: everybody has, the counter is clean for the next launch
+                    if (t == in_class - 1) __hip_atomic_store(&ctrl[cls], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_tk = t;
+                }
+                __syncthreads();
+                const int tk = (int)s_tk;
+                tile = cls + 8 * (tk >> 1);
+                helper = (tk & 1) != 0;
             }
         }
     }
@@ -1034,7 +1036,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
             GANQ_TRACE(0, s, 3);
             // (the barrier waited for every wave's stores: the panel's block is in memory before the helper hears of it)
-            if (duo && tid == 0 && s >= 1) __hip_atomic_store(&ctrl[1 + 5 * tile], tag | (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (duo && tid == 0 && s >= 1) __hip_atomic_store(&ctrl[8 + 5 * tile], tag | (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
             GANQ_TRACE(0, s, 4);
         }
@@ -1168,8 +1170,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             const __amdgpu_buffer_rsrc_t rsrcM = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);  // the tile's blocks
             const __amdgpu_buffer_rsrc_t rsrcF =
                 __builtin_amdgcn_make_buffer_rsrc(Facc + (int64_t)tile * (nb + 1) * SBLK, 0, 0xffffffff, 0x00020000);
-            const uint32_t* solved = ctrl + 1 + 5 * tile;
-            uint32_t* ready = ctrl + 1 + 5 * tile + 1 + gw;
+            const uint32_t* solved = ctrl + 8 + 5 * tile;
+            uint32_t* ready = ctrl + 8 + 5 * tile + 1 + gw;
             int have = nb;  // lowest panel copied so far
             for (int s = 1; s <= nb - 1; ++s) {
                 const int c = s - 1;
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                     if (h > 0) {
                         int ok = 0;
                         if (lane == 0) {
-                            const uint32_t* ready = ctrl + 1 + 5 * tile + 1 + gw;
+                            const uint32_t* ready = ctrl + 8 + 5 * tile + 1 + gw;
                             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
                             for (;;) {
                                 const uint32_t v = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

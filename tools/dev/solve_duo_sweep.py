@@ -22,8 +22,8 @@ def run(m, n):
 _lib.debug_option("GANQ_SOLVE_DUO", 0)
 print("without:", "  ".join(f"{m}x{n} {run(m, n):.3f}" for (m, n) in shapes), flush=True)
 _lib.debug_option("GANQ_SOLVE_DUO", 1)
-pols = [(38, 12, 2, 8), (38, 12, 1, 4), (32, 12, 2, 8), (44, 12, 2, 8), (38, 8, 2, 8), (38, 16, 2, 8), (26, 6, 2, 6), (20, 4, 1, 4),
-        (48, 16, 2, 8), (32, 16, 2, 8), (26, 12, 2, 8), (16, 0, 2, 8), (0, 0, 2, 4), (0, 0, 4, 8), (0, 0, 8, 12), (64, 24, 2, 8)]
+pols = [(44, 12, 2, 8), (44, 10, 2, 8), (44, 8, 2, 8), (48, 12, 2, 8), (52, 16, 2, 8), (52, 12, 2, 8), (44, 10, 3, 8), (44, 10, 2, 12),
+        (44, 10, 2, 5), (40, 8, 2, 8), (40, 6, 2, 8), (36, 4, 2, 8), (48, 10, 2, 8), (56, 16, 2, 8)]
 for pol in pols:
     for name, v in zip(("GANQ_SOLVE_DUO_XA", "GANQ_SOLVE_DUO_XB", "GANQ_SOLVE_DUO_XMIN", "GANQ_SOLVE_DUO_CMIN"), pol):
         _lib.debug_option(name, v)
