@@ -24,6 +24,7 @@
 // b = S (W H) accumulated in fp64 the closed-form loss has no cancellation problem, so no (W-Wq)@H product is
 // needed per iteration.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "update_t.h"
@@ -55,6 +56,7 @@ constexpr int TR = TW * RW;     // rows of W per workgroup
 constexpr int VCH = 32 * VH;    // v columns per chunk (32 per MFMA column tile)
 constexpr int UT = ACC_UT;      // u per staged tile (UT / 64 MFMA steps of 64)
 constexpr int KS64 = UT / 64;
+static_assert(KS64 >= 2, "the code masks are requested KS64 - 1 steps ahead");
 constexpr int UC16 = UT / 16;   // 16-byte pieces per tile row
 constexpr int NP = 8;           // chunk c belongs to part c % NP; every part writes one partial A
 constexpr int BROW = UT + 16;   // LDS row pitch of a digit tile in bytes (pad against bank conflicts)
@@ -209,6 +211,10 @@ __global__ __launch_bounds__(256) void code_masks_kernel(const uint8_t* __restri
             const unsigned long long mk = __ballot(q == a);
             if ((uint32_t)lane == a) mine = mk;
         }
+        // stored with the two middle 16-bit quarters swapped: dword kb of the word then holds, low half first, the bits of columns
+        // 16 kb .. 16 kb + 15 and 32 + 16 kb .. 47 + 16 kb -- exactly what lane half kb of onehot_accum_kernel expands in the two
+        // 32-column halves of a step (one 4-byte load per step instead of an 8-byte one)
+        mine = (mine & 0xffff00000000ffffull) | ((mine & 0x00000000ffff0000ull) << 16) | ((mine & 0x0000ffff00000000ull) >> 16);
         if (lane < 16) bits[item * 16 + lane] = mine;
     }
 }
@@ -286,10 +292,30 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 
     const int nchunk = (n + VCH - 1) / VCH;
     const int ntile = (n + UT - 1) / UT;
+    // code masks of this lane's (row, code): one dword per 64-column step (see code_masks_kernel), requested KS64 - 1 steps
+    // ahead of their use -- one step ahead (round 2) every step waited for its masks: a step is 16 matrix instructions, half a
+    // trip to L2
+    uint32_t wb[KS64][RW / 2];
+    const uint32_t* bits32 = reinterpret_cast<const uint32_t*>(bits);
+    auto load_masks = [&](int gi, uint32_t (&dst)[RW / 2]) {
+#pragma unroll
+        for (int p = 0; p < RW / 2; ++p) dst[p] = gi < ng ? bits32[(((int64_t)mrow[p] * ng + gi) * 16 + a16) * 2 + kb] : 0u;
+    };
+    // The first digit tile and the first masks of a chunk are requested during the LAST tile of the chunk before it (round 3:
+    // a chunk used to open with a load, a store and two barriers in a row -- 7 % of the kernel by its cycle stamps); only the
+    // very first chunk of a workgroup waits for them here.  (t_first grows with the chunk: the first chunk past the last tile
+    // ends the loop.)
+    if (part < nchunk && (part * VCH + 1) / UT < ntile) {
+        gload(part * VCH, (part * VCH + 1) / UT);
+#pragma unroll
+        for (int i = 0; i < KS64 - 1; ++i) load_masks((part * VCH + 1) / UT * KS64 + i, wb[i]);
+    }
     for (int c = part; c < nchunk; c += NP) {
         const int v0 = c * VCH;
         const int t_first = (v0 + 1) / UT;
-        if (t_first >= ntile) continue;
+        if (t_first >= ntile) break;
+        const int v0n = (c + NP) * VCH, tfn = (v0n + 1) / UT;  // the workgroup's next chunk
+        const bool has_next = c + NP < nchunk && tfn < ntile;
         v16i acc[RW / 2][VH][NPL];
 #pragma unroll
         for (int p = 0; p < RW / 2; ++p)
@@ -302,20 +328,19 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
 
         st_t0 = __builtin_amdgcn_s_memtime();
         __syncthreads();  // previous chunk's last tile fully consumed
-        gload(v0, t_first);
         sstore(0);
         __syncthreads();
-        // code masks of this lane's (row, code), one 64-column step ahead of their use
-        unsigned long long wb[2][RW / 2];
-        auto load_masks = [&](int gi, unsigned long long (&dst)[RW / 2]) {
-#pragma unroll
-            for (int p = 0; p < RW / 2; ++p) dst[p] = gi < ng ? bits[((int64_t)mrow[p] * ng + gi) * 16 + a16] : 0ull;
-        };
-        load_masks(t_first * KS64, wb[0]);
         { const long long tt = __builtin_amdgcn_s_memtime(); st_pro += tt - st_t0; st_t0 = tt; }
-        for (int t = t_first; t < ntile; ++t) {
+        // one staged tile of UT columns u.  Only the chunk's FIRST tile can touch the diagonal (t_first = (v0 + 1) / UT, so every later
+        // tile starts right of v0): its 32-column halves are tested one by one; the others run without a branch in the loop, so the
+        // LDS reads of the next half stay in flight across the matrix instructions of this one
+        auto tile_body = [&](auto diag_tag, int t) {
+            constexpr bool DIAG = decltype(diag_tag)::value;
             const int buf = (t - t_first) & 1;
             if (t + 1 < ntile) gload(v0, t + 1);
+            else if (has_next) gload(v0n, tfn);  // (filed by the next chunk's opening)
+            // masks of the steps behind this tile: the next tile's, or the first ones of the next chunk
+            const int gnext = t + 1 < ntile ? (t + 1) * KS64 : (has_next ? tfn * KS64 : ng);
             const char* Bt = Bbuf + buf * BTILE + i32 * BROW + 16 * kb;
             auto read_b = [&](int ks, int kh, v4i (&bf)[VH][NPL]) {
 #pragma unroll
@@ -328,15 +353,15 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
             read_b(0, 0, bf[0]);
 #pragma unroll
             for (int ks = 0; ks < KS64; ++ks) {
-                load_masks(t * KS64 + ks + 1, wb[(ks + 1) & 1]);  // next step (possibly of the next tile)
+                load_masks(ks == 0 ? t * KS64 + KS64 - 1 : gnext + ks - 1, wb[(ks + KS64 - 1) % KS64]);  // KS64 - 1 steps ahead
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) {
                     const int hh = ks * 2 + kh;
                     if (hh + 1 < 2 * KS64) read_b((hh + 1) >> 1, (hh + 1) & 1, bf[(hh + 1) & 1]);  // next 32-column half
-                    if (t * UT + ks * 64 + kh * 32 + 31 <= v0) continue;  // entirely on or above the diagonal (uniform)
+                    if (DIAG && t * UT + ks * 64 + kh * 32 + 31 <= v0) continue;  // entirely on or above the diagonal (uniform)
 #pragma unroll
                     for (int p = 0; p < RW / 2; ++p) {
-                        const uint32_t b16 = (uint32_t)(wb[ks & 1][p] >> (32 * kh + 16 * kb)) & 0xffffu;
+                        const uint32_t b16 = (wb[ks][p] >> (16 * kh)) & 0xffffu;
                         v4i af;
 #pragma unroll
                         for (int d = 0; d < 4; ++d) af[d] = (int)((((b16 >> (4 * d)) & 0xfu) * 0x00204081u) & 0x01010101u);
@@ -350,7 +375,9 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
             }
             if (t + 1 < ntile) sstore(buf ^ 1);
             __syncthreads();
-        }
+        };
+        tile_body(std::true_type{}, t_first);
+        for (int t = t_first + 1; t < ntile; ++t) tile_body(std::false_type{}, t);
         { const long long tt = __builtin_amdgcn_s_memtime(); st_loop += tt - st_t0; st_t0 = tt; }
         // bucket the chunk's columns by their code: Mrow[row][a][b] += sum_d 256^d Y_d[(row, a)][v], b = Q[row][v]
         // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
