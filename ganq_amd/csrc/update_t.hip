@@ -847,6 +847,13 @@ __global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8
     for (int e = tid; e < cnt; e += MG_WAVES * 64) qp[list[e]] = qn[list[e]];
 }
 
+__device__ __forceinline__ void lds_add(double* p, double v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(long long* p, long long v) {
+    (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <typename WHT>
 __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict__ Mpart, const long long* __restrict__ Mpart_lo,
                                                      const TPrep* __restrict__ prep, const int* __restrict__ hdiag_int,
@@ -889,30 +896,42 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
     {
         const uint8_t* q = Q + (int64_t)rowc * n;
         const WHT* wh = WH + (int64_t)rowc * n;
-        const int nfull = n / 128;  // whole blocks of 8 x 16 columns: unconditional loads
-        for (int blk = 0; blk < nfull; ++blk) {
-            const int u0 = blk * 128 + l;
-            int av[8], hv[8];
-            double wv8[8];
+        // whole blocks of KB x 16 columns: unconditional loads, all of a block's requests sent before its first element is
+        // used -- the wave is alone on its SIMD, a block is one trip to L2 (blocks of 8 elements per lane: 32 trips in a row at
+        // n = 4096, half of this kernel's time; 32 elements: 8)
+        auto blocks = [&](auto kb_tag, int u_begin, int count) {
+            constexpr int KB = decltype(kb_tag)::value;
+            for (int blk = 0; blk < count; ++blk) {
+                const int u0 = u_begin + blk * (16 * KB) + l;
+                int av[KB], hv[KB];
+                double wv8[KB];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                av[k] = min((int)q[u0 + 16 * k], 15);
-                wv8[k] = (double)wh[u0 + 16 * k];
-                hv[k] = hdiag_int[u0 + 16 * k];
-            }
+                for (int k = 0; k < KB; ++k) {
+                    av[k] = min((int)q[u0 + 16 * k], 15);
+                    wv8[k] = (double)wh[u0 + 16 * k];
+                    hv[k] = hdiag_int[u0 + 16 * k];
+                }
+                // LDS atomics without a return value instead of read-modify-write: a `+=` on a bucket is a dependent LDS round
+                // trip per element (two buckets may be the same one, so the compiler keeps them in order); ds_add_f64 /
+                // ds_add_u64 are sent off in program order -- the LDS executes a wave's operations in order, so every bucket
+                // still sums its elements in ascending column order, the same bits as before
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                B0[l][av[k]] += wv8[k];
-                Di[rs][l][av[k]] += (long long)hv[k];
+                for (int k = 0; k < KB; ++k) {
+                    lds_add(&B0[l][av[k]], wv8[k]);
+                    lds_add(&Di[rs][l][av[k]], (long long)hv[k]);
+                }
             }
-        }
-        for (int u = nfull * 128 + l; u < n; u += 16) {
+        };
+        const int nbig = n / 512, nfull = (n - nbig * 512) / 128;
+        blocks(std::integral_constant<int, 32>{}, 0, nbig);
+        blocks(std::integral_constant<int, 8>{}, nbig * 512, nfull);
+        for (int u = nbig * 512 + nfull * 128 + l; u < n; u += 16) {
             const int a = min((int)q[u], 15);
-            B0[l][a] += (double)wh[u];
-            Di[rs][l][a] += (long long)hdiag_int[u];
+            lds_add(&B0[l][a], (double)wh[u]);
+            lds_add(&Di[rs][l][a], (long long)hdiag_int[u]);
         }
         if (ext)
-            for (int u = l; u < n; u += 16) Dj[rs][l][min((int)q[u], 15)] += (long long)hdiag_j[u];
+            for (int u = l; u < n; u += 16) lds_add(&Dj[rs][l][min((int)q[u], 15)], (long long)hdiag_j[u]);
     }
     wave_sync();
     double bsum = 0.0;
