@@ -70,6 +70,7 @@ enum Opt : int {
     OPT_SOLVE_DUO_XB,
     OPT_SOLVE_DUO_XMIN,
     OPT_SOLVE_DUO_CMIN,
+    OPT_HESS_SPLIT,
     OPT_COUNT
 };
 long long opt_get(int id);

@@ -59,33 +59,13 @@ __device__ unsigned long long g_hess_trace[8];  // developer: cycles of workgrou
 #define HESS_T(k) do {} while (0)
 #endif
 
+// ---- one tile's sum over a run of tokens: acc[i][j] += X[:, u-block]^T X[:, v-block] for the token rows [0, rows) of X ------------
+// (shared by the whole-tile kernel and the token-split kernel below; Xs = the workgroup's slab buffers)
 template <bool BF16>
-__global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows,
-                                                      int n, float decay, float scale, int tiles_per_side,
-                                                      const uint32_t* __restrict__ tile_order) {
-    __shared__ __align__(16) uint16_t Xs[2][2][HK][HP];  // [operand][buffer][token][feature]; reused by the epilogue
-    uint16_t(*Xa)[HK][HP] = Xs[0];
-    uint16_t(*Xb)[HK][HP] = Xs[1];
-
-    // blockIdx.x enumerates the lower-triangular tile pairs (tu >= tv) through a table in Z (Morton) order, and the
-    // workgroups an XCD receives (every 8th) are mapped to one contiguous run of it: the 32 CUs behind one L2 then work
-    // on a compact patch of H that needs ~16 of the 32 column blocks of X instead of all of them, which keeps the
-    // token slabs they stream L2-resident even when the workgroups drift apart (PMC: 62 % L2 hits, 230 MB fetched per
-    // 2048-token batch of a 16 MB X before this).
-    int tu = 0, tv = 0;
-    {
-        int b = blockIdx.x;
-        const int nblk = (int)gridDim.x;
-        if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
-        const uint32_t pr = tile_order[b];
-        tu = (int)(pr >> 16);
-        tv = (int)(pr & 0xffffu);
-    }
-    (void)tiles_per_side;
-    const int u0 = tu * HT, v0 = tv * HT;
+__device__ __forceinline__ void hess_tile_sum(uint16_t (*Xa)[HK][HP], uint16_t (*Xb)[HK][HP], const uint16_t* __restrict__ X, int rows, int n,
+                                              int u0, int v0, f32x16 (&acc)[2][2]) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
-
     // staging: slab = 32 tokens x 128 features = 512 x 16 B per operand, 2 per thread
     // four slabs of registers in rotation: the loads of slab s+3 are issued while slab s is multiplied (a slab's 64
     // MFMA-cycles are far shorter than one trip to L2 / HBM, and a tile is a chain of rows/32 such trips)
@@ -161,14 +141,6 @@ __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, 
         }
     };
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
     // transposed-read addressing (cdna guide T10): per 16-lane group, lane 4q+p supplies row q, columns 4p..4p+3
     // and receives column (lane & 15), rows 0..3.  MFMA operand lane l: row/col = l & 31, k = 8*(l >> 5) + j.
     const int g16 = (lane >> 4) & 1, kh = lane >> 5, q = (lane & 15) >> 2, p = lane & 3;
@@ -222,6 +194,13 @@ __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, 
     if (fast) mainloop(std::true_type{});
     else mainloop(std::false_type{});
 
+}
+
+// ---- a finished tile: H <- H * decay + scale * acc on the tile and, off the diagonal, on its mirror image ------------------------------
+__device__ __forceinline__ void hess_tile_finish(float* __restrict__ H, int n, int u0, int v0, bool diagonal, float decay, float scale,
+                                                 f32x16 (&acc)[2][2], char* lds_scratch) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
     // direct tile: H[u][v], lanes along v (128 B runs), read-modify-write with the running-average decay
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -240,12 +219,11 @@ __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, 
                 }
                 acc[i][j][r] = val;
             }
-    if (tu == tv) return;
+    if (diagonal) return;
     // mirror tile H[v][u]: transposed through LDS (the slab buffers are free now) so that it is written in 128 B
     // runs as well -- as 4-byte scattered stores it cost more than everything else in the kernel together
     __syncthreads();
-    float(*Tr)[65] = reinterpret_cast<float(*)[65]>(reinterpret_cast<char*>(&Xs[0][0][0][0]) + wv * (32 * 65 * sizeof(float)));
-    static_assert(4 * 32 * 65 * sizeof(float) <= sizeof(Xs), "transpose scratch must fit the slab buffers");
+    float(*Tr)[65] = reinterpret_cast<float(*)[65]>(lds_scratch + wv * (32 * 65 * sizeof(float)));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -263,6 +241,128 @@ __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows,
+                                                      int n, float decay, float scale, int tiles_per_side,
+                                                      const uint32_t* __restrict__ tile_order) {
+    __shared__ __align__(16) uint16_t Xs[2][2][HK][HP];  // [operand][buffer][token][feature]; reused by the epilogue
+    uint16_t(*Xa)[HK][HP] = Xs[0];
+    uint16_t(*Xb)[HK][HP] = Xs[1];
+
+    // blockIdx.x enumerates the lower-triangular tile pairs (tu >= tv) through a table in Z (Morton) order, and the
+    // workgroups an XCD receives (every 8th) are mapped to one contiguous run of it: the 32 CUs behind one L2 then work
+    // on a compact patch of H that needs ~16 of the 32 column blocks of X instead of all of them, which keeps the
+    // token slabs they stream L2-resident even when the workgroups drift apart (PMC: 62 % L2 hits, 230 MB fetched per
+    // 2048-token batch of a 16 MB X before this).
+    int tu = 0, tv = 0;
+    {
+        int b = blockIdx.x;
+        const int nblk = (int)gridDim.x;
+        if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
+        const uint32_t pr = tile_order[b];
+        tu = (int)(pr >> 16);
+        tv = (int)(pr & 0xffffu);
+    }
+    (void)tiles_per_side;
+    const int u0 = tu * HT, v0 = tv * HT;
+    static_assert(4 * 32 * 65 * sizeof(float) <= sizeof(Xs), "transpose scratch must fit the slab buffers");
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    hess_tile_sum<BF16>(Xa, Xb, X, rows, n, u0, v0, acc);
+    hess_tile_finish(H, n, u0, v0, tu == tv, decay, scale, acc, reinterpret_cast<char*>(&Xs[0][0][0][0]));
+}
+
+// ---- token-split launches (round 3) ---------------------------------------------------------------------------------------------
+// The whole-tile kernel gives a workgroup one 128 x 128 tile of H and all the tokens.  That fills the chip only when there are
+// several tiles per workgroup slot (3 per CU by registers and LDS: 768): at n = 4096 the 528 tiles leave 16 CUs with three
+// workgroups and the rest with two -- the launch lasts as long as the CUs with three --, at n = 3072 there are 300 tiles, at
+// n = 2048 136 for 256 CUs, at n = 768 21.  Here the first `bulk` tiles of the Z curve (a multiple of the CU count) keep one
+// workgroup each and all the tokens; every other tile is cut into `parts` equal token ranges, one workgroup each, which fill
+// the remaining slots.  All tiles are cut at the SAME tokens and workgroups of one part are neighbours in the grid: like the
+// whole tiles they walk the tokens in step and share the slabs of X they stream through the L2s (cutting the linear
+// (tile, slab) space into equal runs, every workgroup at its own token offset, was measured first: 643 us against 420 for whole
+// tiles at 16384 x 4096 -- every tile then streams its 8 MB of X from HBM by itself).  A part is stored as a partial tile (the
+// accumulators in register order, coalesced); hessian_fix_kernel adds a tile's parts IN TOKEN ORDER and finishes it: no atomics,
+// no waiting between workgroups, the same bits whatever the scheduling.
+constexpr int HSK_SLOTS_PER_CU = 3;
+constexpr int HSK_PART_FLOATS = HT * HT;  // one partial tile: [64 accumulator registers][256 threads]
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 3) void hessian_sk_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows, int n,
+                                                         float decay, float scale, const uint32_t* __restrict__ tile_order,
+                                                         int bulk, int rest, int part_slabs, float* __restrict__ partial) {
+    __shared__ __align__(16) uint16_t Xs[2][2][HK][HP];
+    static_assert(4 * 32 * 65 * sizeof(float) <= sizeof(Xs), "transpose scratch must fit the slab buffers");
+    int w = blockIdx.x, ti, t_begin = 0, t_end = rows, slot = -1;
+    if (w < bulk) {
+        // the workgroups an XCD receives (every 8th) take one contiguous run of the Z curve, as in the whole-tile kernel
+        if ((bulk & 7) == 0) w = (w & 7) * (bulk >> 3) + (w >> 3);
+        ti = w;
+    } else {
+        slot = w - bulk;  // part-major: the workgroups of one part (one token range) follow each other
+        const int part = slot / rest;
+        ti = bulk + slot % rest;
+        t_begin = min(rows, part * part_slabs * HK);
+        t_end = min(rows, (part + 1) * part_slabs * HK);
+    }
+    const uint32_t pr = tile_order[ti];
+    const int tu = (int)(pr >> 16), tv = (int)(pr & 0xffffu);
+    const int u0 = tu * HT, v0 = tv * HT;
+    const int tid = threadIdx.x;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if (t_end > t_begin) hess_tile_sum<BF16>(Xs[0], Xs[1], X + (int64_t)t_begin * n, t_end - t_begin, n, u0, v0, acc);
+    if (slot < 0) {
+        hess_tile_finish(H, n, u0, v0, tu == tv, decay, scale, acc, reinterpret_cast<char*>(&Xs[0][0][0][0]));
+    } else {
+        float* dst = partial + (int64_t)slot * HSK_PART_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((i * 2 + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+    }
+}
+
+// one workgroup per cut tile: the sum of its parts in token order, then the same finish as everywhere
+__global__ __launch_bounds__(256) void hessian_fix_kernel(float* __restrict__ H, int n, float decay, float scale,
+                                                         const uint32_t* __restrict__ tile_order, int bulk, int rest, int parts,
+                                                         const float* __restrict__ partial) {
+    __shared__ __align__(16) char scratch[4 * 32 * 65 * sizeof(float)];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+    for (int part = 0; part < parts; ++part) {
+        const float* src = partial + ((int64_t)part * rest + j) * HSK_PART_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] += src[((i * 2 + jj) * 16 + r) * 256 + tid];
+    }
+    const uint32_t pr = tile_order[bulk + j];
+    const int tu = (int)(pr >> 16), tv = (int)(pr & 0xffffu);
+    hess_tile_finish(H, n, tu * HT, tv * HT, tu == tv, decay, scale, acc, scratch);
 }
 
 }  // namespace ganq
@@ -310,6 +410,42 @@ const uint32_t* tile_table(int tiles, hipStream_t stream) {
     g_tables.push_back({device, tiles, dev});
     return dev;
 }
+// scratch of the token-split launches: partial tiles, one buffer per (device, stream) -- launches on one stream are ordered, two
+// streams never share a buffer
+struct SkScratch {
+    int device;
+    hipStream_t stream;
+    float* buf;
+    size_t bytes;
+};
+std::vector<SkScratch> g_sk_scratch;
+std::mutex g_sk_mu;
+float* sk_scratch(hipStream_t stream, size_t bytes) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    for (SkScratch& t : g_sk_scratch)
+        if (t.device == device && t.stream == stream) {
+            if (t.bytes >= bytes) return t.buf;
+            return nullptr;  // (sized for the largest launch the first time: see below)
+        }
+    if (g_sk_scratch.size() >= 16) return nullptr;  // many streams: they use the whole-tile kernel
+    float* buf = nullptr;
+    if (hipMalloc(&buf, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    g_sk_scratch.push_back({device, stream, buf, bytes});
+    return buf;
+}
+int device_cus() {
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v;
+    }();
+    return ncu;
+}
 }  // namespace
 
 #ifdef GANQ_HESS_TRACE
@@ -343,6 +479,37 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
     // (in_features beyond ~6.7 M would make a piece a single slab and every piece a read-modify-write of H; no layer is near)
     const int64_t piece_max = std::max<int64_t>(HK, (((int64_t)1 << 31) / (2 * n) - 4 * HK - 1) / HK * HK);
     const uint16_t* Xp = static_cast<const uint16_t*>(X);
+    // Fewer tiles than workgroup slots: cut the tokens of the tiles beyond a multiple of the CU count (hessian_sk_kernel).  Whole
+    // 128-column tiles and 16-byte rows only (every tile on the kernel's fast path), one piece; a part is at least 32 slabs and a
+    // tile has at most 40 parts (the fix-up reads a tile's parts one after the other).  Measured, 16384 tokens (a staged group):
+    // n = 768 194 -> 68 us, 2048 204 -> 131, 3072 289 -> 261, 4096 420 -> 385; a single sequence of 2048 tokens loses 10-30 %
+    // to the second launch and stays on the whole-tile kernel.
+    const int ncu = device_cus(), slots = HSK_SLOTS_PER_CU * ncu;
+    const int64_t nslab = (rows + HK - 1) / HK;
+    if (opt_get(OPT_HESS_SPLIT) != 0 && rows > 0 && rows <= piece_max && (n % HT) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+        ncu >= 8 && blocks < slots && nslab >= 128) {
+        const int bulk = blocks / ncu * ncu, rest = blocks - bulk;
+        int parts = rest > 0 ? (int)std::min<int64_t>(std::min<int64_t>((slots - bulk) / rest, nslab / 32), 40) : 0;
+        if (opt_get(OPT_HESS_SPLIT) > 1) parts = (int)std::min<long long>(parts, opt_get(OPT_HESS_SPLIT));  // developer: cap the parts
+        if (parts >= 2) {
+            const int part_slabs = (int)(((nslab + parts - 1) / parts + 3) / 4 * 4);  // whole rounds of four slabs
+            parts = (int)((nslab + part_slabs - 1) / part_slabs);                     // (no empty parts)
+            float* part = sk_scratch(stream, (size_t)slots * HSK_PART_FLOATS * sizeof(float));
+            if (part && parts >= 2 && (int64_t)rest * parts <= slots) {
+                const unsigned grid = (unsigned)(bulk + rest * parts);
+                if (dtype == 1)
+                    hipLaunchKernelGGL(hessian_sk_kernel<true>, dim3(grid), dim3(256), 0, stream, H, Xp, (int)rows, (int)n, decay, scale, order,
+                                       bulk, rest, part_slabs, part);
+                else
+                    hipLaunchKernelGGL(hessian_sk_kernel<false>, dim3(grid), dim3(256), 0, stream, H, Xp, (int)rows, (int)n, decay, scale, order,
+                                       bulk, rest, part_slabs, part);
+                hipLaunchKernelGGL(hessian_fix_kernel, dim3((unsigned)rest), dim3(256), 0, stream, H, (int)n, decay, scale, order, bulk, rest,
+                                   parts, part);
+                GANQ_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
     int64_t done = 0;
     do {
         const int64_t piece = std::min(rows - done, piece_max);

@@ -50,6 +50,7 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"GANQ_SOLVE_DUO_XB", 12},
     {"GANQ_SOLVE_DUO_XMIN", 2},
     {"GANQ_SOLVE_DUO_CMIN", 8},
+    {"GANQ_HESS_SPLIT", 1},        // Hessian: 0 = whole-tile kernel only; 1 = cut the tokens of the tiles beyond a multiple of the CU count when tiles < workgroup slots; > 1: at most this many parts per tile
 };
 
 std::atomic<long long> g_opt[OPT_COUNT];

@@ -91,6 +91,35 @@ def test_hessian_vs_oracle_shapes(hip, oracle, rows, n, dtype):
         assert rel_fro(H.cpu().numpy(), Ho) < 1e-6
 
 
+@pytest.mark.parametrize("rows,n,dtype", [(4096, 768, torch.float16), (5000, 1280, torch.bfloat16), (16384, 2048, torch.float16),
+                                          (4101, 3072, torch.float16)])
+def test_hessian_token_split_launches(hip, rows, n, dtype, lib_options):
+    """Layers with fewer 128 x 128 tiles than workgroup slots cut the tokens of some tiles into parts (hessian_sk_kernel) and add
+    the parts in token order (hessian_fix_kernel).  Same products, another grouping of the fp32 sums: equal to the whole-tile
+    kernel to fp32 rounding, exactly symmetric, run-to-run identical, the running average's decay applied once; ragged token
+    counts (last part shorter, last slab partial) included."""
+    g = torch.Generator().manual_seed(rows + n)
+    X1 = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
+    X2 = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
+    outs = {}
+    for split in (0, 1, 3):
+        lib_options(GANQ_HESS_SPLIT=split)
+        H = torch.full((n, n), 7.0, device="cuda")  # stale contents must be ignored on the first batch
+        hip.hessian_accum(H, X1, 0, 2)
+        hip.hessian_accum(H, X2, 2, 3)              # H * 2/5 + (2/5) X2^T X2
+        outs[split] = H
+    ref = (2.0 / 5.0) * (X1.double().T @ X1.double() + X2.double().T @ X2.double())
+    for split in (1, 3):
+        assert torch.equal(outs[split], outs[split].T)
+        assert float((outs[split].double() - ref).norm() / ref.norm()) < 1e-6
+        assert float((outs[split] - outs[0]).abs().max() / outs[0].abs().max()) < 1e-5
+    lib_options(GANQ_HESS_SPLIT=1)
+    H = torch.full((n, n), 7.0, device="cuda")
+    hip.hessian_accum(H, X1, 0, 2)
+    hip.hessian_accum(H, X2, 2, 3)
+    assert torch.equal(H, outs[1])  # deterministic: no atomics, fixed order
+
+
 # ------------------------------------------------------------------------------------------ Cholesky (prologue)
 @pytest.mark.parametrize("n", [1, 5, 127, 128, 129, 300, 1000, 2048])
 def test_cholesky_vs_fp64(hip, n):
