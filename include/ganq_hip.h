@@ -78,7 +78,9 @@ int ganq_kmeans_init(const float* W, const double* col_weight, int64_t m, int64_
 /* ---- a4/a5: S-solve (ganq.py:533-565 torch branch == Metal kernel compute_s :39-270) --------
  * W [m,n], L [n,n] lower-triangular with leading dimension ldl, T [m,V].
  * Q_out [m,n] uint8.  Err_out [m,n] fp32 (W - T[Q]; the Metal kernel's `Werr`) or NULL.
- * workspace: ganq_solve_s_workspace_bytes().                                                  */
+ * workspace: ganq_solve_s_workspace_bytes() -- the per-tile Err scratch and the packed copy of L, plus the
+ * hand-over buffers of the helper workgroups that launches with at most half as many 16-row tiles as
+ * the chip has CUs use (csrc/solve_s.hip, "duo"); contents need no initialisation.              */
 size_t ganq_solve_s_workspace_bytes(int64_t m, int64_t n, int V);
 int ganq_solve_s(const float* W, const float* L, int64_t ldl, const float* T, int64_t m, int64_t n, int V,
                  uint8_t* Q_out, float* Err_out, void* workspace, size_t workspace_bytes, void* stream);
