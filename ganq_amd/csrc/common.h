@@ -71,6 +71,9 @@ enum Opt : int {
     OPT_SOLVE_DUO_XMIN,
     OPT_SOLVE_DUO_CMIN,
     OPT_HESS_SPLIT,
+    OPT_HESS_WIDE,
+    OPT_HESS_BULK,
+    OPT_HESS_PARTS,
     OPT_COUNT
 };
 long long opt_get(int id);

@@ -60,84 +60,97 @@ __device__ unsigned long long g_hess_trace[8];  // developer: cycles of workgrou
 #endif
 
 // ---- one tile's sum over a run of tokens: acc[i][j] += X[:, u-block]^T X[:, v-block] for the token rows [0, rows) of X ------------
-// (shared by the whole-tile kernel and the token-split kernel below; Xs = the workgroup's slab buffers)
-template <bool BF16>
-__device__ __forceinline__ void hess_tile_sum(uint16_t (*Xa)[HK][HP], uint16_t (*Xb)[HK][HP], const uint16_t* __restrict__ X, int rows, int n,
-                                              int u0, int v0, f32x16 (&acc)[2][2]) {
+// (shared by the whole-tile kernel and the token-split kernels below)
+// MH = 128-row blocks of the tile (1: 128 x 128, 4 waves; 2: 256 x 128, 8 waves -- 85 instead of 64 flop per byte streamed out of
+// the L2s).  Xs = the workgroup's slab buffers, [buffer][image][token][feature] with images 0 .. MH-1 = the u blocks, MH = the v block.
+template <bool BF16, int MH>
+__device__ __forceinline__ void hess_tile_sum(uint16_t (*Xs)[HK][HP], const uint16_t* __restrict__ X, int rows, int n, int u0, int v0,
+                                              f32x16 (&acc)[2][2]) {
+    constexpr int NT = 256 * MH;       // threads
+    constexpr int NIMG = MH + 1;
+    constexpr int HLA = HL;            // 16-byte loads per thread and slab: u operand (MH x 512 pieces over NT threads)
+    constexpr int HLB = HL / MH;       // ... v operand (512 pieces)
+    static_assert(HL % MH == 0, "the v operand must split evenly over the threads");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
-    // staging: slab = 32 tokens x 128 features = 512 x 16 B per operand, 2 per thread
+    const int wmi = wv >> 1, wn = (wv & 1) * 64;  // this wave: rows 64 wmi .. +63 of the tile, columns wn .. +63
+    auto img = [&](int buf, int i) -> uint16_t (*)[HP] { return Xs[buf * NIMG + i]; };
+    // staging: slab = 32 tokens x 128 features = 512 x 16 B per image
     // four slabs of registers in rotation: the loads of slab s+3 are issued while slab s is multiplied (a slab's 64
     // MFMA-cycles are far shorter than one trip to L2 / HBM, and a tile is a chain of rows/32 such trips)
-    uint4 ra4[4][HL], rb4[4][HL];
+    constexpr int RD = MH == 1 ? 4 : 3;  // slabs of registers in rotation (the 8-wave shape has 128 registers per lane)
+    uint4 ra4[RD][HLA], rb4[RD][HLB];
     // fast path (uniform per workgroup): full, 16-byte aligned tile columns -> unconditional loads (a token row past
     // the end is clamped and zeroed afterwards), so that the compiler can count the loads in flight instead of
     // draining them at every slab
     // (rows == 0, an empty batch, only decays H: the fast path's clamp to row rows-1 would read out of bounds)
-    const bool fast = rows > 0 && (u0 + HT <= n) && (v0 + HT <= n) && ((n & 7) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+    const bool fast = rows > 0 && (u0 + HT * MH <= n) && (v0 + HT <= n) && ((n & 7) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                       ((int64_t)(rows + 4 * HK) * n * 2 < (1ll << 31));  // 32-bit offsets of the buffer loads (incl. the look-ahead)
-    // byte offsets of this thread's chunks inside a slab (token row idx >> 4, feature chunk idx & 15); a slab spans at most
-    // HK * n * 2 bytes, far below 4 GB
-    uint32_t offA[HL], offB[HL];
+    // this thread's pieces of a slab: u operand piece idx = (token row, 16-byte piece of the MH x 128 features), v operand likewise
+    // with 16 pieces per row; byte offsets inside a slab (a slab spans at most HK * n * 2 bytes, far below 4 GB)
+    auto rowA = [&](int h) { return (h * NT + tid) / (16 * MH); };
+    auto colA = [&](int h) { return ((h * NT + tid) % (16 * MH)) * 8; };
+    auto rowB = [&](int h) { return (h * NT + tid) >> 4; };
+    auto colB = [&](int h) { return ((h * NT + tid) & 15) * 8; };
+    uint32_t offA[HLA], offB[HLB];
 #pragma unroll
-    for (int h = 0; h < HL; ++h) {
-        const int idx = h * 256 + tid;
-        offA[h] = (uint32_t)(((idx >> 4) * n + u0 + (idx & 15) * 8) * 2);
-        offB[h] = (uint32_t)(((idx >> 4) * n + v0 + (idx & 15) * 8) * 2);
-    }
+    for (int h = 0; h < HLA; ++h) offA[h] = (uint32_t)((rowA(h) * n + u0 + colA(h)) * 2);
+#pragma unroll
+    for (int h = 0; h < HLB; ++h) offB[h] = (uint32_t)((rowB(h) * n + v0 + colB(h)) * 2);
     const __amdgpu_buffer_rsrc_t rsrcX =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X), 0, (int)((int64_t)rows * n * 2), 0x00020000);
-    auto gload = [&](auto fast_tag, int t0, uint4 (&ra)[HL], uint4 (&rb)[HL]) {
+    auto gload = [&](auto fast_tag, int t0, uint4 (&ra)[HLA], uint4 (&rb)[HLB]) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        if constexpr (FAST) {
+            // (rows past the end are zeroed where the slab is filed, in sstore: a select HERE makes the compiler wait for the
+            // load it has just issued -- vmcnt(0) right behind every pair of loads, the whole round trip exposed per slab)
+            // buffer loads: the slab's byte offset in an SGPR, this thread's constant offset inside a slab in a VGPR -- no
+            // per-load 64-bit address arithmetic (it was a fifth of a slab step: 610 of 2900 cycles by the stamps); the
+            // resource ends with the last token row, so rows past the end read as zeros by themselves
+            // Token rows past the end exist only in the last slabs (and the look-ahead behind them).  For THOSE the slab
+            // offset travels in the VGPR offset, which the hardware compares with num_records in every addressing mode
+            // (offset >= num_records reads 0, nothing is fetched); whether the SGPR offset takes part in that comparison
+            // differs between descriptions of the gfx9 family, and this kernel does not depend on it.
+            const int soff = t0 * n * 2;
+            const bool past = t0 + HK > rows;  // uniform
+            const int so = past ? 0 : soff, vo = past ? soff : 0;
 #pragma unroll
-        for (int h = 0; h < HL; ++h) {
-            const int idx = h * 256 + tid;
-            const int t = t0 + (idx >> 4), f8 = (idx & 15) * 8;
-            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-            if constexpr (FAST) {
-                // (rows past the end are zeroed where the slab is filed, in sstore: a select HERE makes the compiler wait for the
-                // load it has just issued -- vmcnt(0) right behind every pair of loads, the whole round trip exposed per slab)
-                // buffer loads: the slab's byte offset in an SGPR, this thread's constant offset inside a slab in a VGPR -- no
-                // per-load 64-bit address arithmetic (it was a fifth of a slab step: 610 of 2900 cycles by the stamps); the
-                // resource ends with the last token row, so rows past the end read as zeros by themselves
-                // Token rows past the end exist only in the last slabs (and the look-ahead behind them).  For THOSE the slab
-                // offset travels in the VGPR offset, which the hardware compares with num_records in every addressing mode
-                // (offset >= num_records reads 0, nothing is fetched); whether the SGPR offset takes part in that comparison
-                // differs between descriptions of the gfx9 family, and this kernel does not depend on it.
-                (void)t;
-                (void)f8;
-                const int soff = t0 * n * 2;
-                const bool past = t0 + HK > rows;  // uniform
-                const int so = past ? 0 : soff, vo = past ? soff : 0;
-                va = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offA[h] + vo, so, 0));
-                vb = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offB[h] + vo, so, 0));
-            } else {
-              if (t < rows) {
-                const uint16_t* pa = X + (int64_t)t * n + u0 + f8;
-                const uint16_t* pb = X + (int64_t)t * n + v0 + f8;
-                uint16_t tmp[8];
-                for (int e = 0; e < 8; ++e) tmp[e] = (u0 + f8 + e < n) ? pa[e] : (uint16_t)0;
-                va = *reinterpret_cast<uint4*>(tmp);
-                for (int e = 0; e < 8; ++e) tmp[e] = (v0 + f8 + e < n) ? pb[e] : (uint16_t)0;
-                vb = *reinterpret_cast<uint4*>(tmp);
-              }
-            }
-            ra[h] = va;
-            rb[h] = vb;
+            for (int h = 0; h < HLA; ++h)
+                ra[h] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offA[h] + vo, so, 0));
+#pragma unroll
+            for (int h = 0; h < HLB; ++h)
+                rb[h] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)offB[h] + vo, so, 0));
+        } else {
+            auto ragged = [&](int t, int f0) -> uint4 {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (t < rows) {
+                    const uint16_t* pa = X + (int64_t)t * n + f0;
+                    uint16_t tmp[8];
+                    for (int e = 0; e < 8; ++e) tmp[e] = (f0 + e < n) ? pa[e] : (uint16_t)0;
+                    v = *reinterpret_cast<uint4*>(tmp);
+                }
+                return v;
+            };
+#pragma unroll
+            for (int h = 0; h < HLA; ++h) ra[h] = ragged(t0 + rowA(h), u0 + colA(h));
+#pragma unroll
+            for (int h = 0; h < HLB; ++h) rb[h] = ragged(t0 + rowB(h), v0 + colB(h));
         }
     };
     // t0 = first token of the slab: a slab that reaches past `rows` (uniform per workgroup: only the last ones do) has
     // its surplus token rows zeroed here
-    auto sstore = [&](int buf, int t0, const uint4 (&ra)[HL], const uint4 (&rb)[HL]) {
+    auto sstore = [&](int buf, int t0, const uint4 (&ra)[HLA], const uint4 (&rb)[HLB]) {
         const bool tail = t0 + HK > rows;
 #pragma unroll
-        for (int h = 0; h < HL; ++h) {
-            const int idx = h * 256 + tid;
-            const int t = idx >> 4, f8 = (idx & 15) * 8;
-            uint4 va = ra[h], vb = rb[h];
-            if (tail && t0 + t >= rows) va = vb = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(&Xa[buf][t][f8]) = va;
-            *reinterpret_cast<uint4*>(&Xb[buf][t][f8]) = vb;
+        for (int h = 0; h < HLA; ++h) {
+            uint4 va = ra[h];
+            if (tail && t0 + rowA(h) >= rows) va = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&img(buf, MH == 1 ? 0 : (colA(h) >> 7))[rowA(h)][colA(h) & 127]) = va;
+        }
+#pragma unroll
+        for (int h = 0; h < HLB; ++h) {
+            uint4 vb = rb[h];
+            if (tail && t0 + rowB(h) >= rows) vb = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&img(buf, MH)[rowB(h)][colB(h)]) = vb;
         }
     };
 
@@ -154,13 +167,16 @@ __device__ __forceinline__ void hess_tile_sum(uint16_t (*Xa)[HK][HP], uint16_t (
 
     const int nslab = (rows + HK - 1) / HK;
     auto compute = [&](int buf) {
+        const uint16_t (*Sa)[HP] = img(buf, MH == 1 ? 0 : (wmi >> 1));
+        const uint16_t (*Sb)[HP] = img(buf, MH);
+        const int wm = (wmi & 1) * 64;
 #pragma unroll
         for (int kk = 0; kk < HK; kk += 16) {
             s8v a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = frag(Xa[buf], kk, wm + 32 * i);
+            for (int i = 0; i < 2; ++i) a[i] = frag(Sa, kk, wm + 32 * i);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = frag(Xb[buf], kk, wn + 32 * j);
+            for (int j = 0; j < 2; ++j) b[j] = frag(Sb, kk, wn + 32 * j);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -168,23 +184,22 @@ __device__ __forceinline__ void hess_tile_sum(uint16_t (*Xa)[HK][HP], uint16_t (
         }
     };
     auto mainloop = [&](auto fast_tag) {
-        gload(fast_tag, 0, ra4[0], rb4[0]);
-        gload(fast_tag, HK, ra4[1], rb4[1]);
-        gload(fast_tag, 2 * HK, ra4[2], rb4[2]);
+#pragma unroll
+        for (int d = 0; d < RD - 1; ++d) gload(fast_tag, d * HK, ra4[d], rb4[d]);
         sstore(0, 0, ra4[0], rb4[0]);
         __syncthreads();
-        // whole rounds of four slabs; slabs past the end are zeros (they add nothing)
+        // whole rounds of RD slabs; slabs past the end are zeros (they add nothing)
 #ifdef GANQ_HESS_TRACE
         unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
-        for (int s = 0; s < nslab; s += 4) {
+        for (int s = 0; s < nslab; s += RD) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                gload(fast_tag, (s + jj + 3) * HK, ra4[(jj + 3) & 3], rb4[(jj + 3) & 3]);
+            for (int jj = 0; jj < RD; ++jj) {
+                gload(fast_tag, (s + jj + RD - 1) * HK, ra4[(jj + RD - 1) % RD], rb4[(jj + RD - 1) % RD]);
                 HESS_T(0);
                 compute((s + jj) & 1);
                 HESS_T(1);
-                sstore((s + jj + 1) & 1, (s + jj + 1) * HK, ra4[(jj + 1) & 3], rb4[(jj + 1) & 3]);
+                sstore((s + jj + 1) & 1, (s + jj + 1) * HK, ra4[(jj + 1) % RD], rb4[(jj + 1) % RD]);
                 HESS_T(2);
                 __syncthreads();
                 HESS_T(3);
@@ -193,14 +208,17 @@ __device__ __forceinline__ void hess_tile_sum(uint16_t (*Xa)[HK][HP], uint16_t (
     };
     if (fast) mainloop(std::true_type{});
     else mainloop(std::false_type{});
-
 }
 
 // ---- a finished tile: H <- H * decay + scale * acc on the tile and, off the diagonal, on its mirror image ------------------------------
-__device__ __forceinline__ void hess_tile_finish(float* __restrict__ H, int n, int u0, int v0, bool diagonal, float decay, float scale,
+// mode 0: a tile below the diagonal (direct + mirror); 1: a square tile ON the diagonal, computed in full (X^T X is symmetric), so
+// it needs no mirror; 2: a 256 x 128 tile that crosses the diagonal: element (u, v) is written directly where u >= v and mirrored
+// where u > v, so that every element of H is written exactly once (the read-modify-write with the decay must not happen twice)
+__device__ __forceinline__ void hess_tile_finish(float* __restrict__ H, int n, int u0, int v0, int mode, float decay, float scale,
                                                  f32x16 (&acc)[2][2], char* lds_scratch) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const bool pred = mode == 2;
     // direct tile: H[u][v], lanes along v (128 B runs), read-modify-write with the running-average decay
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -211,45 +229,64 @@ __device__ __forceinline__ void hess_tile_finish(float* __restrict__ H, int n, i
                 const int u = u0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int v = v0 + wn + 32 * j + (lane & 31);
                 float val = 0.0f;
-                if (u < n && v < n) {
+                if (u < n && v < n && (!pred || u >= v)) {
                     const int64_t o = (int64_t)u * n + v;
                     const float old = (decay != 0.0f) ? H[o] * decay : 0.0f;
                     val = old + scale * acc[i][j][r];
-                    H[o] = val;  // a diagonal tile is computed in full (X^T X is symmetric), so it needs no mirror
+                    H[o] = val;
                 }
                 acc[i][j][r] = val;
             }
-    if (diagonal) return;
+    if (mode == 1) return;
     // mirror tile H[v][u]: transposed through LDS (the slab buffers are free now) so that it is written in 128 B
     // runs as well -- as 4-byte scattered stores it cost more than everything else in the kernel together
     __syncthreads();
-    float(*Tr)[65] = reinterpret_cast<float(*)[65]>(lds_scratch + wv * (32 * 65 * sizeof(float)));
+    // (one 32 x 32 block of the wave's 64 x 64 at a time: 4.2 KB of scratch per wave, so that eight waves stay inside the slab buffers)
+    float(*Tr)[33] = reinterpret_cast<float(*)[33]>(lds_scratch + wv * (32 * 33 * sizeof(float)));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Tr[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][32 * j + (lane & 31)] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int rr = lane & 31;
-        const int u = u0 + wm + 32 * i + rr;
-        for (int cc = lane >> 5; cc < 64; cc += 2) {
-            const int v = v0 + wn + cc;
-            if (u < n && v < n) H[(int64_t)v * n + u] = Tr[rr][cc];
+            for (int r = 0; r < 16; ++r) Tr[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int rr = lane & 31;
+            const int u = u0 + wm + 32 * i + rr;
+            for (int cc = lane >> 5; cc < 32; cc += 2) {
+                const int v = v0 + wn + 32 * j + cc;
+                if (u < n && v < n && (!pred || u > v)) H[(int64_t)v * n + u] = Tr[rr][cc];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
+}
+
+// tile shape MH: workgroup threads, floats of a partial tile, LDS bytes (slab buffers; the finish's transpose scratch, 4224 B per wave)
+template <int MH> struct HessShape {
+    static constexpr int NT = 256 * MH;
+    static constexpr int PART_FLOATS = HT * HT * MH;
+    static constexpr size_t SLAB_BYTES = (size_t)2 * (MH + 1) * HK * HP * sizeof(uint16_t);
+    static constexpr size_t SCRATCH_BYTES = (size_t)4 * MH * 32 * 33 * sizeof(float);
+    static constexpr size_t LDS_BYTES = SLAB_BYTES > SCRATCH_BYTES ? SLAB_BYTES : SCRATCH_BYTES;
+    static constexpr int WGS_PER_CU = MH == 1 ? 3 : 2;
+};
+// tile table entry -> first row / column and finish mode
+template <int MH>
+__device__ __forceinline__ void hess_tile_of(uint32_t pr, int& u0, int& v0, int& mode) {
+    const int tu = (int)(pr >> 16), tv = (int)(pr & 0xffffu);
+    u0 = tu * HT * MH;
+    v0 = tv * HT;
+    if (MH == 1) mode = tu == tv ? 1 : 0;
+    else mode = v0 + HT > u0 ? 2 : 0;  // some column of the tile lies right of its first row: it crosses the diagonal
 }
 
 template <bool BF16>
 __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows,
                                                       int n, float decay, float scale, int tiles_per_side,
                                                       const uint32_t* __restrict__ tile_order) {
-    __shared__ __align__(16) uint16_t Xs[2][2][HK][HP];  // [operand][buffer][token][feature]; reused by the epilogue
-    uint16_t(*Xa)[HK][HP] = Xs[0];
-    uint16_t(*Xb)[HK][HP] = Xs[1];
+    __shared__ __align__(16) uint16_t Xs[2][2][HK][HP];  // [buffer][operand][token][feature]; reused by the epilogue
 
     // blockIdx.x enumerates the lower-triangular tile pairs (tu >= tv) through a table in Z (Morton) order, and the
     // workgroups an XCD receives (every 8th) are mapped to one contiguous run of it: the 32 CUs behind one L2 then work
@@ -267,7 +304,7 @@ __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, 
     }
     (void)tiles_per_side;
     const int u0 = tu * HT, v0 = tv * HT;
-    static_assert(4 * 32 * 65 * sizeof(float) <= sizeof(Xs), "transpose scratch must fit the slab buffers");
+    static_assert(HessShape<1>::SCRATCH_BYTES <= sizeof(Xs), "transpose scratch must fit the slab buffers");
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -276,8 +313,8 @@ __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    hess_tile_sum<BF16>(Xa, Xb, X, rows, n, u0, v0, acc);
-    hess_tile_finish(H, n, u0, v0, tu == tv, decay, scale, acc, reinterpret_cast<char*>(&Xs[0][0][0][0]));
+    hess_tile_sum<BF16, 1>(&Xs[0][0], X, rows, n, u0, v0, acc);
+    hess_tile_finish(H, n, u0, v0, tu == tv ? 1 : 0, decay, scale, acc, reinterpret_cast<char*>(&Xs[0][0][0][0]));
 }
 
 // ---- token-split launches (round 3) ---------------------------------------------------------------------------------------------
@@ -292,15 +329,14 @@ __global__ __launch_bounds__(256, 3) void hessian_kernel(float* __restrict__ H, 
 // tiles at 16384 x 4096 -- every tile then streams its 8 MB of X from HBM by itself).  A part is stored as a partial tile (the
 // accumulators in register order, coalesced); hessian_fix_kernel adds a tile's parts IN TOKEN ORDER and finishes it: no atomics,
 // no waiting between workgroups, the same bits whatever the scheduling.
-constexpr int HSK_SLOTS_PER_CU = 3;
-constexpr int HSK_PART_FLOATS = HT * HT;  // one partial tile: [64 accumulator registers][256 threads]
-
-template <bool BF16>
-__global__ __launch_bounds__(256, 3) void hessian_sk_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows, int n,
-                                                         float decay, float scale, const uint32_t* __restrict__ tile_order,
-                                                         int bulk, int rest, int part_slabs, float* __restrict__ partial) {
-    __shared__ __align__(16) uint16_t Xs[2][2][HK][HP];
-    static_assert(4 * 32 * 65 * sizeof(float) <= sizeof(Xs), "transpose scratch must fit the slab buffers");
+template <bool BF16, int MH>
+__global__ __launch_bounds__(256 * MH, MH == 1 ? 3 : 4) void hessian_sk_kernel(float* __restrict__ H, const uint16_t* __restrict__ X, int rows,
+                                                                            int n, float decay, float scale,
+                                                                            const uint32_t* __restrict__ tile_order, int bulk, int rest,
+                                                                            int part_slabs, float* __restrict__ partial) {
+    using Shape = HessShape<MH>;
+    __shared__ __align__(16) char smem[Shape::LDS_BYTES];
+    uint16_t(*Xs)[HK][HP] = reinterpret_cast<uint16_t(*)[HK][HP]>(smem);
     int w = blockIdx.x, ti, t_begin = 0, t_end = rows, slot = -1;
     if (w < bulk) {
         // the workgroups an XCD receives (every 8th) take one contiguous run of the Z curve, as in the whole-tile kernel
@@ -313,9 +349,8 @@ __global__ __launch_bounds__(256, 3) void hessian_sk_kernel(float* __restrict__ 
         t_begin = min(rows, part * part_slabs * HK);
         t_end = min(rows, (part + 1) * part_slabs * HK);
     }
-    const uint32_t pr = tile_order[ti];
-    const int tu = (int)(pr >> 16), tv = (int)(pr & 0xffffu);
-    const int u0 = tu * HT, v0 = tv * HT;
+    int u0, v0, mode;
+    hess_tile_of<MH>(tile_order[ti], u0, v0, mode);
     const int tid = threadIdx.x;
     f32x16 acc[2][2];
 #pragma unroll
@@ -324,25 +359,27 @@ __global__ __launch_bounds__(256, 3) void hessian_sk_kernel(float* __restrict__ 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    if (t_end > t_begin) hess_tile_sum<BF16>(Xs[0], Xs[1], X + (int64_t)t_begin * n, t_end - t_begin, n, u0, v0, acc);
+    if (t_end > t_begin) hess_tile_sum<BF16, MH>(Xs, X + (int64_t)t_begin * n, t_end - t_begin, n, u0, v0, acc);
     if (slot < 0) {
-        hess_tile_finish(H, n, u0, v0, tu == tv, decay, scale, acc, reinterpret_cast<char*>(&Xs[0][0][0][0]));
+        hess_tile_finish(H, n, u0, v0, mode, decay, scale, acc, smem);
     } else {
-        float* dst = partial + (int64_t)slot * HSK_PART_FLOATS;
+        float* dst = partial + (int64_t)slot * Shape::PART_FLOATS;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[((i * 2 + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) dst[((i * 2 + j) * 16 + r) * Shape::NT + tid] = acc[i][j][r];
     }
 }
 
 // one workgroup per cut tile: the sum of its parts in token order, then the same finish as everywhere
-__global__ __launch_bounds__(256) void hessian_fix_kernel(float* __restrict__ H, int n, float decay, float scale,
-                                                         const uint32_t* __restrict__ tile_order, int bulk, int rest, int parts,
-                                                         const float* __restrict__ partial) {
-    __shared__ __align__(16) char scratch[4 * 32 * 65 * sizeof(float)];
+template <int MH>
+__global__ __launch_bounds__(256 * MH) void hessian_fix_kernel(float* __restrict__ H, int n, float decay, float scale,
+                                                              const uint32_t* __restrict__ tile_order, int bulk, int rest, int parts,
+                                                              const float* __restrict__ partial) {
+    using Shape = HessShape<MH>;
+    __shared__ __align__(16) char scratch[Shape::SCRATCH_BYTES];
     const int j = blockIdx.x, tid = threadIdx.x;
     f32x16 acc[2][2];
 #pragma unroll
@@ -352,17 +389,17 @@ __global__ __launch_bounds__(256) void hessian_fix_kernel(float* __restrict__ H,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
     for (int part = 0; part < parts; ++part) {
-        const float* src = partial + ((int64_t)part * rest + j) * HSK_PART_FLOATS;
+        const float* src = partial + ((int64_t)part * rest + j) * Shape::PART_FLOATS;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] += src[((i * 2 + jj) * 16 + r) * 256 + tid];
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] += src[((i * 2 + jj) * 16 + r) * Shape::NT + tid];
     }
-    const uint32_t pr = tile_order[bulk + j];
-    const int tu = (int)(pr >> 16), tv = (int)(pr & 0xffffu);
-    hess_tile_finish(H, n, tu * HT, tv * HT, tu == tv, decay, scale, acc, scratch);
+    int u0, v0, mode;
+    hess_tile_of<MH>(tile_order[bulk + j], u0, v0, mode);
+    hess_tile_finish(H, n, u0, v0, mode, decay, scale, acc, scratch);
 }
 
 }  // namespace ganq
@@ -371,7 +408,7 @@ using namespace ganq;
 
 namespace {
 struct TileTable {
-    int device, tiles;
+    int device, tiles, mh, count;
     uint32_t* dev;
 };
 std::vector<TileTable> g_tables;
@@ -389,27 +426,35 @@ uint32_t morton2(uint32_t x, uint32_t y) {
     return spread(x) | (spread(y) << 1);
 }
 
-// lower-triangular tile pairs (tu << 16 | tv) sorted along the Z curve; cached per device and tile count
-const uint32_t* tile_table(int tiles, hipStream_t stream) {
+// lower-triangular tile pairs (tu << 16 | tv) sorted along the Z curve; cached per device, tile count and tile height
+// (mh = 1: 128 x 128 tiles, tv <= tu; mh = 2: 256 rows x 128 columns, every tile with an element on or below the diagonal:
+// tv <= 2 tu + 1).  `tiles` = 128-column blocks per side; *count = tiles in the table.
+const uint32_t* tile_table(int tiles, int mh, int* count) {
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_tables_mu);
     for (const TileTable& t : g_tables)
-        if (t.device == device && t.tiles == tiles) return t.dev;
+        if (t.device == device && t.tiles == tiles && t.mh == mh) {
+            *count = t.count;
+            return t.dev;
+        }
     std::vector<std::pair<uint32_t, uint32_t>> keyed;
-    for (int tu = 0; tu < tiles; ++tu)
-        for (int tv = 0; tv <= tu; ++tv) keyed.push_back({morton2((uint32_t)tv, (uint32_t)tu), ((uint32_t)tu << 16) | (uint32_t)tv});
+    const int rows_blocks = (tiles + mh - 1) / mh;
+    for (int tu = 0; tu < rows_blocks; ++tu)
+        for (int tv = 0; tv < tiles && tv <= mh * tu + (mh - 1); ++tv)
+            keyed.push_back({morton2((uint32_t)tv, (uint32_t)(mh * tu)), ((uint32_t)tu << 16) | (uint32_t)tv});
     std::sort(keyed.begin(), keyed.end());
     std::vector<uint32_t> host(keyed.size());
     for (size_t i = 0; i < keyed.size(); ++i) host[i] = keyed[i].second;
     uint32_t* dev = nullptr;
     if (hipMalloc(&dev, host.size() * sizeof(uint32_t)) != hipSuccess) return nullptr;
-    // synchronous copy on purpose (pageable host memory, once per shape); the stream argument is only ordered after it
+    // synchronous copy on purpose (pageable host memory, once per shape)
     if (hipMemcpy(dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    (void)stream;
-    g_tables.push_back({device, tiles, dev});
+    g_tables.push_back({device, tiles, mh, (int)host.size(), dev});
+    *count = (int)host.size();
     return dev;
 }
+
 // scratch of the token-split launches: partial tiles, one buffer per (device, stream) -- launches on one stream are ordered, two
 // streams never share a buffer
 struct SkScratch {
@@ -469,8 +514,8 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
     const float decay = (float)((double)nsamples_before / total);
     const float scale = (float)(2.0 / total);
     const int tiles = (int)((n + HT - 1) / HT);
-    const int blocks = tiles * (tiles + 1) / 2;
-    const uint32_t* order = tile_table(tiles, stream);
+    int blocks = 0;
+    const uint32_t* order = tile_table(tiles, 1, &blocks);
     if (!order) return fail(-100, "ganq_hessian_accum: could not build the tile table");
     ProfScope prof(KID_HESSIAN, stream);
     // The kernel's fast path addresses X through 32-bit buffer offsets: a batch of more than ~2 GB goes in pieces of whole
@@ -479,36 +524,67 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
     // (in_features beyond ~6.7 M would make a piece a single slab and every piece a read-modify-write of H; no layer is near)
     const int64_t piece_max = std::max<int64_t>(HK, (((int64_t)1 << 31) / (2 * n) - 4 * HK - 1) / HK * HK);
     const uint16_t* Xp = static_cast<const uint16_t*>(X);
-    // Fewer tiles than workgroup slots: cut the tokens of the tiles beyond a multiple of the CU count (hessian_sk_kernel).  Whole
-    // 128-column tiles and 16-byte rows only (every tile on the kernel's fast path), one piece; a part is at least 32 slabs and a
-    // tile has at most 40 parts (the fix-up reads a tile's parts one after the other).  Measured, 16384 tokens (a staged group):
-    // n = 768 194 -> 68 us, 2048 204 -> 131, 3072 289 -> 261, 4096 420 -> 385; a single sequence of 2048 tokens loses 10-30 %
-    // to the second launch and stays on the whole-tile kernel.
-    const int ncu = device_cus(), slots = HSK_SLOTS_PER_CU * ncu;
+    // Staged groups of batches (>= 128 slabs) on layers whose every tile is on the kernels' fast path go through
+    // hessian_sk_kernel: tiles beyond a multiple of the CU count have their tokens cut into parts that fill the remaining
+    // workgroup slots (at least 32 slabs per part, at most 40 parts per tile: the fix-up reads a tile's parts one after the
+    // other), and -- GANQ_HESS_WIDE -- the tiles are 256 x 128 where in_features allows.  Measured, 16384 tokens: see DESIGN.md.
+    // A single sequence of 2048 tokens loses 10-30 % to a second launch and stays on the whole-tile kernel.
+    const int ncu = device_cus();
     const int64_t nslab = (rows + HK - 1) / HK;
-    if (opt_get(OPT_HESS_SPLIT) != 0 && rows > 0 && rows <= piece_max && (n % HT) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
-        ncu >= 8 && blocks < slots && nslab >= 128) {
-        const int bulk = blocks / ncu * ncu, rest = blocks - bulk;
-        int parts = rest > 0 ? (int)std::min<int64_t>(std::min<int64_t>((slots - bulk) / rest, nslab / 32), 40) : 0;
-        if (opt_get(OPT_HESS_SPLIT) > 1) parts = (int)std::min<long long>(parts, opt_get(OPT_HESS_SPLIT));  // developer: cap the parts
-        if (parts >= 2) {
-            const int part_slabs = (int)(((nslab + parts - 1) / parts + 3) / 4 * 4);  // whole rounds of four slabs
-            parts = (int)((nslab + part_slabs - 1) / part_slabs);                     // (no empty parts)
-            float* part = sk_scratch(stream, (size_t)slots * HSK_PART_FLOATS * sizeof(float));
-            if (part && parts >= 2 && (int64_t)rest * parts <= slots) {
-                const unsigned grid = (unsigned)(bulk + rest * parts);
-                if (dtype == 1)
-                    hipLaunchKernelGGL(hessian_sk_kernel<true>, dim3(grid), dim3(256), 0, stream, H, Xp, (int)rows, (int)n, decay, scale, order,
-                                       bulk, rest, part_slabs, part);
-                else
-                    hipLaunchKernelGGL(hessian_sk_kernel<false>, dim3(grid), dim3(256), 0, stream, H, Xp, (int)rows, (int)n, decay, scale, order,
-                                       bulk, rest, part_slabs, part);
-                hipLaunchKernelGGL(hessian_fix_kernel, dim3((unsigned)rest), dim3(256), 0, stream, H, (int)n, decay, scale, order, bulk, rest,
-                                   parts, part);
-                GANQ_LAUNCH_CHECK();
-                return 0;
+    const bool sk_ok = rows > 0 && rows <= piece_max && (n % HT) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ncu >= 8 && nslab >= 128;
+    auto launch_sk = [&](auto mh_tag, bool whole_only) -> int {  // 1: launched, 0: not applicable, < 0: error
+        constexpr int MH = decltype(mh_tag)::value;
+        using Shape = HessShape<MH>;
+        int count = 0;
+        const uint32_t* ord = tile_table(tiles, MH, &count);
+        if (!ord) return fail(-100, "ganq_hessian_accum: could not build the tile table");
+        const int slots = Shape::WGS_PER_CU * ncu;
+        int bulk = count, rest = 0, parts = 1, part_slabs = (int)nslab;
+        float* part = nullptr;
+        if (opt_get(OPT_HESS_SPLIT) != 0 && count % ncu != 0) {
+            // the tiles beyond a multiple of the CU count are cut: into the slots the bulk leaves free when everything is resident
+            // at once, else into one round of slots behind the bulk's rounds
+            bulk = count / ncu * ncu;
+            if (opt_get(OPT_HESS_BULK) >= 0) bulk = (int)std::min<long long>(bulk, opt_get(OPT_HESS_BULK) / ncu * ncu);  // developer
+            rest = count - bulk;
+            const int free_slots = count < slots ? slots - bulk : slots;
+            parts = (int)std::min<int64_t>(std::min<int64_t>(free_slots / rest, nslab / 32), 40);
+            if (opt_get(OPT_HESS_SPLIT) > 1) parts = (int)std::min<long long>(parts, opt_get(OPT_HESS_SPLIT));  // developer: cap the parts
+            if (opt_get(OPT_HESS_PARTS) > 0) parts = (int)std::min<long long>(opt_get(OPT_HESS_PARTS), nslab / 4);  // developer: force them
+            if (parts >= 2) {
+                part_slabs = (int)(((nslab + parts - 1) / parts + 3) / 4 * 4);  // whole rounds of four slabs
+                parts = (int)((nslab + part_slabs - 1) / part_slabs);           // (no empty parts)
+                if ((int64_t)rest * parts <= (int64_t)6 * ncu / MH)             // what the scratch holds
+                    part = sk_scratch(stream, (size_t)6 * ncu * HT * HT * sizeof(float));  // 6 ncu x 64 KB = 3 ncu x 128 KB (96 MB)
+            }
+            if (parts < 2 || !part) {
+                bulk = count;
+                rest = 0;
+                parts = 1;
             }
         }
+        if (rest == 0 && !whole_only) return 0;  // nothing to cut: the caller's whole-tile path
+        const unsigned grid = (unsigned)(bulk + rest * parts);
+        if (dtype == 1)
+            hipLaunchKernelGGL((hessian_sk_kernel<true, MH>), dim3(grid), dim3(Shape::NT), 0, stream, H, Xp, (int)rows, (int)n, decay, scale, ord,
+                               bulk, rest, part_slabs, part);
+        else
+            hipLaunchKernelGGL((hessian_sk_kernel<false, MH>), dim3(grid), dim3(Shape::NT), 0, stream, H, Xp, (int)rows, (int)n, decay, scale, ord,
+                               bulk, rest, part_slabs, part);
+        if (rest > 0)
+            hipLaunchKernelGGL(hessian_fix_kernel<MH>, dim3((unsigned)rest), dim3(Shape::NT), 0, stream, H, (int)n, decay, scale, ord, bulk, rest,
+                               parts, part);
+        GANQ_LAUNCH_CHECK();
+        return 1;
+    };
+    if (sk_ok) {
+        // 256 x 128 tiles from 3072 in_features on (measured, 16384 tokens: n = 3072 284 -> 233 us, 14336 5720 -> 3815; below, the
+        // few wide tiles leave CUs with one 8-wave workgroup: n = 2048 136 vs 145 us, 768 81 vs 91); GANQ_HESS_WIDE=2 forces them
+        const long long wide = opt_get(OPT_HESS_WIDE);
+        int rc = 0;
+        if (wide != 0 && (n % (2 * HT)) == 0 && (wide == 2 || n >= 3072)) rc = launch_sk(std::integral_constant<int, 2>{}, true);
+        else if (opt_get(OPT_HESS_SPLIT) != 0) rc = launch_sk(std::integral_constant<int, 1>{}, false);
+        if (rc != 0) return rc < 0 ? rc : 0;
     }
     int64_t done = 0;
     do {

@@ -51,6 +51,9 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"GANQ_SOLVE_DUO_XMIN", 2},
     {"GANQ_SOLVE_DUO_CMIN", 8},
     {"GANQ_HESS_SPLIT", 1},        // Hessian: 0 = whole-tile kernel only; 1 = cut the tokens of the tiles beyond a multiple of the CU count when tiles < workgroup slots; > 1: at most this many parts per tile
+    {"GANQ_HESS_WIDE", 1},         // Hessian, staged groups: 256 x 128 tiles from 3072 in_features on (multiples of 256); 0: never, 2: whenever possible
+    {"GANQ_HESS_BULK", -1},        // Hessian, developer: at most this many whole tiles (the others are cut); -1: as many as fill the CUs evenly
+    {"GANQ_HESS_PARTS", 0},        // Hessian, developer: cut the tiles behind the bulk into exactly this many parts (0: as many as fill the free slots)
 };
 
 std::atomic<long long> g_opt[OPT_COUNT];

@@ -92,32 +92,39 @@ def test_hessian_vs_oracle_shapes(hip, oracle, rows, n, dtype):
 
 
 @pytest.mark.parametrize("rows,n,dtype", [(4096, 768, torch.float16), (5000, 1280, torch.bfloat16), (16384, 2048, torch.float16),
-                                          (4101, 3072, torch.float16)])
+                                          (4101, 3072, torch.float16), (4096, 5120, torch.float16)])
 def test_hessian_token_split_launches(hip, rows, n, dtype, lib_options):
     """Layers with fewer 128 x 128 tiles than workgroup slots cut the tokens of some tiles into parts (hessian_sk_kernel) and add
     the parts in token order (hessian_fix_kernel).  Same products, another grouping of the fp32 sums: equal to the whole-tile
     kernel to fp32 rounding, exactly symmetric, run-to-run identical, the running average's decay applied once; ragged token
-    counts (last part shorter, last slab partial) included."""
+    counts (last part shorter, last slab partial) and a layer with more tiles than slots (n = 5120: only the tiles behind the
+    last full round are cut) included."""
     g = torch.Generator().manual_seed(rows + n)
     X1 = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
     X2 = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
     outs = {}
-    for split in (0, 1, 3):
-        lib_options(GANQ_HESS_SPLIT=split)
+    # (wide, split): 128 x 128 whole tiles (the reference point); 128 x 128 cut; 256 x 128 tiles (where in_features is a multiple
+    # of 256: every shape here) whole / cut / cut into at most 3 parts
+    configs = [(0, 0), (0, 1), (0, 3), (2, 0), (2, 1), (2, 3)]  # (GANQ_HESS_WIDE = 2: wide tiles whatever in_features)
+    for cfg in configs:
+        lib_options(GANQ_HESS_WIDE=cfg[0], GANQ_HESS_SPLIT=cfg[1])
         H = torch.full((n, n), 7.0, device="cuda")  # stale contents must be ignored on the first batch
         hip.hessian_accum(H, X1, 0, 2)
         hip.hessian_accum(H, X2, 2, 3)              # H * 2/5 + (2/5) X2^T X2
-        outs[split] = H
+        outs[cfg] = H
     ref = (2.0 / 5.0) * (X1.double().T @ X1.double() + X2.double().T @ X2.double())
-    for split in (1, 3):
-        assert torch.equal(outs[split], outs[split].T)
-        assert float((outs[split].double() - ref).norm() / ref.norm()) < 1e-6
-        assert float((outs[split] - outs[0]).abs().max() / outs[0].abs().max()) < 1e-5
-    lib_options(GANQ_HESS_SPLIT=1)
-    H = torch.full((n, n), 7.0, device="cuda")
-    hip.hessian_accum(H, X1, 0, 2)
-    hip.hessian_accum(H, X2, 2, 3)
-    assert torch.equal(H, outs[1])  # deterministic: no atomics, fixed order
+    for cfg in configs[1:]:
+        assert torch.equal(outs[cfg], outs[cfg].T), cfg
+        assert float((outs[cfg].double() - ref).norm() / ref.norm()) < 1e-6, cfg
+        assert float((outs[cfg] - outs[(0, 0)]).abs().max() / outs[(0, 0)].abs().max()) < 1e-5, cfg
+    # whole tiles of either shape add the same products in the same order: the same bits
+    assert torch.equal(outs[(2, 0)], outs[(0, 0)])
+    for cfg in ((0, 1), (2, 1)):  # deterministic: no atomics, fixed order
+        lib_options(GANQ_HESS_WIDE=cfg[0], GANQ_HESS_SPLIT=cfg[1])
+        H = torch.full((n, n), 7.0, device="cuda")
+        hip.hessian_accum(H, X1, 0, 2)
+        hip.hessian_accum(H, X2, 2, 3)
+        assert torch.equal(H, outs[cfg]), cfg
 
 
 # ------------------------------------------------------------------------------------------ Cholesky (prologue)
