@@ -1180,14 +1180,22 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                 const int need = nb - h;
                 if (need < have) {  // (uniform over the four waves)
                     // panel p was solved in step nb - p: wait until the tile has announced step h
+                    int seen = 0;
                     if (lane == 0) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
                         for (;;) {
                             const uint32_t v = __hip_atomic_load(solved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)h) break;
+                            if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)h) {
+                                seen = 1;
+                                break;
+                            }
+                            // every spin is bounded: a tile that has not announced a panel for 16 x DUO_TIMEOUT is not coming
+                            // (it gave up on this helper long before); the four waves read the same flag and leave together
+                            if (__builtin_amdgcn_s_memtime() - t0 > 16 * DUO_TIMEOUT) break;
                             __builtin_amdgcn_s_sleep(8);
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
+                    if (!__builtin_amdgcn_readfirstlane(seen)) return;
                     // copy the new blocks: 4 KB each, 16 bytes per thread; into LDS (panels >= pbase) or this workgroup's own
                     // scratch (plain stores and loads from here on: one CU, one L1)
                     for (int pp = have - 1; pp >= need; --pp) {
