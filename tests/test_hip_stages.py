@@ -178,6 +178,30 @@ def test_solve_s_helper_workgroups_bit_identical(hip, oracle, m, n, V, seed, lib
     assert np.array_equal(Q0.cpu().numpy()[rows], oracle.solve_s(W[rows], L, T0[rows]))
 
 
+def test_solve_s_helper_workgroups_on_concurrent_streams(hip):
+    """Two helped launches at once (the looper quantizes the followers of a group on side streams): each asks for 128 tiles + 128
+    helpers, together twice the chip.  Whatever subset of the workgroups is resident, a tile either has its helper or finishes
+    without it -- the indices must be those of the launches run one after the other, and nothing may hang."""
+    outs, data = [], []
+    for seed in (41, 42, 43):
+        W, H, L, T0 = synth(2048, 1024, 16, seed, corr=0.1)
+        data.append((dev(W), dev(L), dev(T0)))
+    ref = [hip.solve_s(*d) for d in data]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in data]
+    for _ in range(3):
+        outs = []
+        for st, d in zip(streams, data):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(hip.solve_s(*d))
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            assert torch.equal(o, r)
+
+
 def test_solve_s_strided_L_and_empty(hip, oracle):
     W, H, L, T0 = synth(16, 96, 16, 10)
     Lbig = torch.zeros(96, 160, device="cuda")
