@@ -576,6 +576,11 @@ __host__ __device__ __forceinline__ int duo_near(int c, int pol) {
     return x < c ? x : c;
 }
 
+#ifndef GANQ_SOLVE_PRIME
+#define GANQ_SOLVE_PRIME 0  // measured: the chains start 0.2-0.5 us earlier and part 2 takes 0.3 us longer -- the chain waves are not
+                            // the critical path of most steps; 4096 x 4096 1.05 vs 1.04 ms.  Off.  (The primed head assumes a chain
+                            // that starts at the top panel: a build with it switches the helper workgroups off.)
+#endif
 template <bool KASC>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __restrict__ W, const float* __restrict__ L,
                                                       int64_t ldl, const float* __restrict__ Lr, int NT,
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     int tile = blockIdx.x;
     bool duo = false, helper = false;
     if constexpr (!SPLIT) {
-        if (duo_pol != 0) {
+        if (duo_pol != 0 && GANQ_SOLVE_PRIME == 0) {
             const int A = (min(nact, m) + SR - 1) / SR;  // active tiles
             duo = A <= DUO_MAX_TILES && 16 * ((A + 7) >> 3) <= min((int)gridDim.x, ncu);
             if (duo) {  // roles by ticket (see above); a launch without helpers keeps tile = blockIdx and draws nothing
@@ -1044,10 +1049,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     }
 #ifndef GANQ_SPLIT_RING
 #define GANQ_SPLIT_RING 4
-#endif
-#ifndef GANQ_SOLVE_PRIME
-#define GANQ_SOLVE_PRIME 0  // measured: the chains start 0.2-0.5 us earlier and part 2 takes 0.3 us longer -- the chain waves are not
-                            // the critical path of most steps; 4096 x 4096 1.05 vs 1.04 ms.  Off.
 #endif
     constexpr int RING = SPLIT ? GANQ_SPLIT_RING : GANQ_SOLVE_RING;
     // the operand ring lives across the steps: the first RING - 1 batches of the NEXT step's chain are requested before this

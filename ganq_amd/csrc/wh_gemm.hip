@@ -53,9 +53,22 @@ __global__ __launch_bounds__(256) void wh_split_w_kernel(const float* __restrict
     __shared__ float sh[4];
     const int r = blockIdx.x, rb = r >> 7, rr = r & 127;
     const float* w = W + (int64_t)min(r, m - 1) * n;
+    // 16-byte loads where the row allows them (every layer shape in use: n a multiple of 8, 16-byte aligned base): with scalar
+    // loads the two split kernels took 170 us of the 0.7 ms the T-update's preparation costs per layer
+    const bool vec = (n & 7) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (reinterpret_cast<uintptr_t>(dexp) & 15) == 0;
     float mx = 0.0f;
-    if (r < m)
-        for (int u = threadIdx.x; u < n; u += 256) mx = fmaxf(mx, fabsf(ldexpf(w[u], dexp[u])));
+    if (r < m) {
+        if (vec) {
+            for (int u4 = threadIdx.x; u4 < n / 4; u4 += 256) {
+                const float4 x = reinterpret_cast<const float4*>(w)[u4];
+                const int4 e = reinterpret_cast<const int4*>(dexp)[u4];
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ldexpf(x.x, e.x)), fabsf(ldexpf(x.y, e.y)))),
+                           fmaxf(fabsf(ldexpf(x.z, e.z)), fabsf(ldexpf(x.w, e.w))));
+            }
+        } else {
+            for (int u = threadIdx.x; u < n; u += 256) mx = fmaxf(mx, fabsf(ldexpf(w[u], dexp[u])));
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
@@ -66,10 +79,19 @@ __global__ __launch_bounds__(256) void wh_split_w_kernel(const float* __restrict
     bool any = false;
     for (int ci = threadIdx.x; ci < KT * 4; ci += 256) {
         h8v hi, lo;
+        float xs8[8];
+        int es8[8];
+        const bool full = vec && r < m && ci * 8 + 8 <= n;  // (padding pieces beyond n and rows beyond m are zeros)
+        if (full) {
+            *reinterpret_cast<float4*>(&xs8[0]) = reinterpret_cast<const float4*>(w)[ci * 2];
+            *reinterpret_cast<float4*>(&xs8[4]) = reinterpret_cast<const float4*>(w)[ci * 2 + 1];
+            *reinterpret_cast<int4*>(&es8[0]) = reinterpret_cast<const int4*>(dexp)[ci * 2];
+            *reinterpret_cast<int4*>(&es8[4]) = reinterpret_cast<const int4*>(dexp)[ci * 2 + 1];
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int u = ci * 8 + k;
-            const float x = (r < m && u < n) ? ldexpf(w[u], dexp[u] + sft) : 0.0f;
+            const float x = full ? ldexpf(xs8[k], es8[k] + sft) : ((r < m && u < n) ? ldexpf(w[u], dexp[u] + sft) : 0.0f);
             const _Float16 h = (_Float16)x;
             const _Float16 l = (_Float16)(x - (float)h);
             hi[k] = h;
@@ -95,14 +117,31 @@ __global__ __launch_bounds__(256) void wh_split_h_kernel(const int* __restrict__
     const bool use_j = *ext != 0;
     const double hs = *hscale;
     const int er = dexp[rc];
+    const bool vec = (n & 7) == 0 && (reinterpret_cast<uintptr_t>(Hint) & 15) == 0 && (reinterpret_cast<uintptr_t>(Jint) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dexp) & 15) == 0;
     for (int ci = threadIdx.x; ci < KT * 4; ci += 256) {
         h8v hi, lo;
+        int hv8[8], es8[8];
+        short jv8[8];
+        const bool full = vec && r < n && ci * 8 + 8 <= n;
+        if (full) {  // 16-byte loads (see wh_split_w_kernel)
+            *reinterpret_cast<int4*>(&hv8[0]) = reinterpret_cast<const int4*>(h)[ci * 2];
+            *reinterpret_cast<int4*>(&hv8[4]) = reinterpret_cast<const int4*>(h)[ci * 2 + 1];
+            *reinterpret_cast<int4*>(&es8[0]) = reinterpret_cast<const int4*>(dexp)[ci * 2];
+            *reinterpret_cast<int4*>(&es8[4]) = reinterpret_cast<const int4*>(dexp)[ci * 2 + 1];
+            if (use_j) *reinterpret_cast<int4*>(&jv8[0]) = reinterpret_cast<const int4*>(hj)[ci];
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int u = ci * 8 + k;
             double x = 0.0;
-            if (r < n && u < n && u != r) {  // the diagonal is added exactly by the GEMM's epilogue
-                const double fx = (double)h[u] + (use_j ? (double)((int)hj[u] - 128) * (1.0 / 65536.0) : 0.0);  // stored biased
+            if (full) {
+                if (u != r) {  // the diagonal is added exactly by the GEMM's epilogue
+                    const double fx = (double)hv8[k] + (use_j ? (double)((int)jv8[k] - 128) * (1.0 / 65536.0) : 0.0);  // stored biased
+                    x = ldexp(fx * hs, 12 - er - es8[k]);
+                }
+            } else if (r < n && u < n && u != r) {
+                const double fx = (double)h[u] + (use_j ? (double)((int)hj[u] - 128) * (1.0 / 65536.0) : 0.0);
                 x = ldexp(fx * hs, 12 - er - dexp[u]);
             }
             const _Float16 a = (_Float16)(float)x;
