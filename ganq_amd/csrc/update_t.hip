@@ -228,13 +228,10 @@ __global__ __launch_bounds__(256) void code_masks_kernel(const uint8_t* __restri
 // NPL digit planes starting at plane P0: <4, 0> sums the 31-bit word I, <2, 4> the extension word J (into its own
 // Mpart; that launch leaves at once when the extension is off)
 template <int NPL, int P0>
-__global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __restrict__ planes_all,
-                                                              const unsigned long long* __restrict__ bits,
-                                                              const uint8_t* __restrict__ Q, int m, int n, int nq, int ng,
-                                                              long long* __restrict__ Mpart, long long* __restrict__ stamps,
-                                                              const long long* __restrict__ changed, long long thr,
-                                                              const TPrep* __restrict__ prep) {
-    if (changed && *changed <= thr) return;
+__device__ __forceinline__ void onehot_accum_body(const int8_t* __restrict__ planes_all, const unsigned long long* __restrict__ bits,
+                                                  const uint8_t* __restrict__ Q, int m, int n, int nq, int ng,
+                                                  long long* __restrict__ Mpart, long long* __restrict__ stamps,
+                                                  const TPrep* __restrict__ prep, const int bid) {
     if (P0 != 0 && prep->ext == 0) return;
     constexpr int BTILE = btile_bytes(NPL);
     const int8_t* planes = planes_all + (int64_t)P0 * n * nq;
@@ -249,7 +246,7 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
     const int i32 = lane & 31, kb = lane >> 5;
     const int r2 = i32 >> 4, a16 = i32 & 15;
     const int nrg = (m + TR - 1) / TR;
-    const int rg = blockIdx.x % nrg, part = blockIdx.x / nrg;
+    const int rg = bid % nrg, part = bid / nrg;
     const int row0 = rg * TR + wv * RW;
     int rowc[RW];
 #pragma unroll
@@ -413,7 +410,7 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
         }
         { const long long tt = __builtin_amdgcn_s_memtime(); st_flush += tt - st_t0; st_t0 = tt; }
     }
-    if (stamps && blockIdx.x == 0 && tid == 0) { stamps[0] = st_pro; stamps[1] = st_loop; stamps[2] = st_flush; }
+    if (stamps && bid == 0 && tid == 0) { stamps[0] = st_pro; stamps[1] = st_loop; stamps[2] = st_flush; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -422,6 +419,20 @@ __global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __r
             long long* out = Mpart + ((int64_t)part * m + row0 + r) * 256;
             for (int i = lane; i < 256; i += 64) out[i] = Mrow[wv][r][i];
         }
+}
+
+// One launch for both words: the first `nblk_hi` workgroups sum the four digit planes of the 31-bit word, the others the two planes
+// of the extension word into its own partial sums (they leave at once when the extension is off).  As two launches the second
+// one cost a dispatch (~5 us on the device) in every iteration of the loop, also when the full accumulation is gated off.
+__global__ __launch_bounds__(TW * 64) void onehot_accum_kernel(const int8_t* __restrict__ planes_all,
+                                                              const unsigned long long* __restrict__ bits,
+                                                              const uint8_t* __restrict__ Q, int m, int n, int nq, int ng,
+                                                              long long* __restrict__ Mpart_hi, long long* __restrict__ Mpart_lo,
+                                                              long long* __restrict__ stamps, const long long* __restrict__ changed,
+                                                              long long thr, const TPrep* __restrict__ prep, int nblk_hi) {
+    if (changed && *changed <= thr) return;
+    if ((int)blockIdx.x < nblk_hi) onehot_accum_body<4, 0>(planes_all, bits, Q, m, n, nq, ng, Mpart_hi, stamps, prep, (int)blockIdx.x);
+    else onehot_accum_body<2, 4>(planes_all, bits, Q, m, n, nq, ng, Mpart_lo, nullptr, prep, (int)blockIdx.x - nblk_hi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -459,14 +470,22 @@ __device__ __forceinline__ void wave_sync() {
 // Mstate[row] = F = M + M^T with M = sum_p Mpart[p][row]; Qprev = Q   (after a full accumulation)
 // is_lo: the sums of the extension word (own Mpart / Mstate; leaves at once when the extension is off; Qprev is the
 // other launch's business)
-__global__ __launch_bounds__(256) void m_reduce_kernel(const long long* __restrict__ Mpart, int m, long long* __restrict__ Mstate,
+__global__ __launch_bounds__(256) void m_reduce_kernel(const long long* __restrict__ Mpart_hi, const long long* __restrict__ Mpart_lo, int m,
+                                                      long long* __restrict__ Mstate_hi, long long* __restrict__ Mstate_lo,
                                                       const uint8_t* __restrict__ Q, uint8_t* __restrict__ Qprev, int64_t qbytes,
                                                       const long long* __restrict__ changed, long long thr,
-                                                      const TPrep* __restrict__ prep, int is_lo) {
+                                                      const TPrep* __restrict__ prep, int nblk_hi) {
     if (changed && *changed <= thr) return;
+    // one launch for both words (a dispatch costs ~5 us on the device even when it leaves at once, and this one sits in every
+    // iteration of the loop): the first nblk_hi workgroups sum the 31-bit word and bring Qprev up to date, the others the extension
+    const int is_lo = (int)blockIdx.x >= nblk_hi;
     if (is_lo && prep->ext == 0) return;
+    const long long* Mpart = is_lo ? Mpart_lo : Mpart_hi;
+    long long* Mstate = is_lo ? Mstate_lo : Mstate_hi;
+    const int64_t bid = is_lo ? (int64_t)blockIdx.x - nblk_hi : (int64_t)blockIdx.x;
+    const int64_t nblk = is_lo ? (int64_t)gridDim.x - nblk_hi : (int64_t)nblk_hi;
     const int64_t total = (int64_t)m * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = bid * 256 + threadIdx.x; i < total; i += nblk * 256) {
         const int64_t it = (i & ~255ll) | ((i & 15) << 4) | ((i >> 4) & 15);  // the transposed cell of the same row
         long long s = 0;
 #pragma unroll
@@ -475,9 +494,9 @@ __global__ __launch_bounds__(256) void m_reduce_kernel(const long long* __restri
     }
     if (is_lo) return;
     const int64_t q16 = qbytes / 16;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < q16; i += (int64_t)gridDim.x * 256)
+    for (int64_t i = bid * 256 + threadIdx.x; i < q16; i += nblk * 256)
         reinterpret_cast<uint4*>(Qprev)[i] = reinterpret_cast<const uint4*>(Q)[i];
-    for (int64_t i = q16 * 16 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < qbytes; i += (int64_t)gridDim.x * 256) Qprev[i] = Q[i];
+    for (int64_t i = q16 * 16 + bid * 256 + threadIdx.x; i < qbytes; i += nblk * 256) Qprev[i] = Q[i];
 }
 
 // one wave per row: columns whose index differs from the previous iteration -> chg[row][0..cnt), chgcnt[row]; *changed += cnt
@@ -1468,11 +1487,9 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
                            (int)lo.ng, bits, gate, thr);
     }
     GANQ_LAUNCH_CHECK();
-    const size_t smem = 2 * (size_t)btile_bytes(4) + (size_t)TW * RW * 256 * sizeof(long long);
-    const size_t smem_lo = 2 * (size_t)btile_bytes(2) + (size_t)TW * RW * 256 * sizeof(long long);
+    const size_t smem = 2 * (size_t)btile_bytes(4) + (size_t)TW * RW * 256 * sizeof(long long);  // (the extension's two planes need less)
     {
-        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(onehot_accum_kernel<4, 0>), smem);
-        if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(onehot_accum_kernel<2, 4>), smem_lo);
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(onehot_accum_kernel), smem);
         if (rc) return rc;
     }
     {
@@ -1481,11 +1498,8 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         const bool dbg = opt_get(OPT_ACCUM_DEBUG) == 1;  // developer timing experiment
         long long* stamps = nullptr;
         if (dbg) (void)hipMalloc(&stamps, 64);
-        hipLaunchKernelGGL((onehot_accum_kernel<4, 0>), dim3((unsigned)(nrg * NP)), dim3(TW * 64), smem, stream, planes, bits, Q, (int)m,
-                           (int)n, (int)lo.nq, (int)lo.ng, mpart, stamps, gate, thr, prep);
-        // the extension word's planes into their own partial sums (leaves at once when the extension is off)
-        hipLaunchKernelGGL((onehot_accum_kernel<2, 4>), dim3((unsigned)(nrg * NP)), dim3(TW * 64), smem_lo, stream, planes, bits, Q,
-                           (int)m, (int)n, (int)lo.nq, (int)lo.ng, mpart_lo, static_cast<long long*>(nullptr), gate, thr, prep);
+        hipLaunchKernelGGL(onehot_accum_kernel, dim3((unsigned)(2 * nrg * NP)), dim3(TW * 64), smem, stream, planes, bits, Q, (int)m, (int)n,
+                           (int)lo.nq, (int)lo.ng, mpart, mpart_lo, stamps, gate, thr, prep, nrg * NP);
         if (stamps) {
             long long h[3];
             (void)hipStreamSynchronize(stream);
@@ -1494,9 +1508,8 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
             fprintf(stderr, "[onehot_accum stamps] wg0 wave0: prologue %lld, tile loop %lld, flush %lld cycles\n", h[0], h[1], h[2]);
         }
         if (stateful) {
-            hipLaunchKernelGGL(m_reduce_kernel, dim3(1024), dim3(256), 0, stream, mpart, (int)m, mstate, Q, qprev, m * n, gate, thr, prep, 0);
-            hipLaunchKernelGGL(m_reduce_kernel, dim3(256), dim3(256), 0, stream, mpart_lo, (int)m, mstate_lo, Q, qprev, m * n, gate, thr,
-                               prep, 1);
+            hipLaunchKernelGGL(m_reduce_kernel, dim3(1024 + 256), dim3(256), 0, stream, mpart, mpart_lo, (int)m, mstate, mstate_lo, Q, qprev,
+                               m * n, gate, thr, prep, 1024);
         }
     }
     GANQ_LAUNCH_CHECK();
