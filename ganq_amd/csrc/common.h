@@ -70,6 +70,9 @@ enum Opt : int {
     OPT_SOLVE_DUO_XB,
     OPT_SOLVE_DUO_XMIN,
     OPT_SOLVE_DUO_CMIN,
+    OPT_SOLVE_TRIO,
+    OPT_SOLVE_TRIO_XA,
+    OPT_SOLVE_TRIO_XB,
     OPT_HESS_SPLIT,
     OPT_HESS_WIDE,
     OPT_HESS_BULK,

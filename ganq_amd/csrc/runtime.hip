@@ -50,6 +50,9 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"GANQ_SOLVE_DUO_XB", 12},
     {"GANQ_SOLVE_DUO_XMIN", 2},
     {"GANQ_SOLVE_DUO_CMIN", 8},
+    {"GANQ_SOLVE_TRIO", 1},        // S-solve: 0 = never two helpers per tile
+    {"GANQ_SOLVE_TRIO_XA", 12},    // ... the tile's share with two helpers: max(XMIN, XA c / 64 - XB)
+    {"GANQ_SOLVE_TRIO_XB", 0},
     {"GANQ_HESS_SPLIT", 1},        // Hessian: 0 = whole-tile kernel only; 1 = cut the tokens of the tiles beyond a multiple of the CU count when tiles < workgroup slots; > 1: at most this many parts per tile
     {"GANQ_HESS_WIDE", 1},         // Hessian, staged groups: 256 x 128 tiles from 3072 in_features on (multiples of 256); 0: never, 2: whenever possible
     {"GANQ_HESS_BULK", -1},        // Hessian, developer: at most this many whole tiles (the others are cut); -1: as many as fill the CUs evenly

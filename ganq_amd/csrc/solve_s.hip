@@ -563,8 +563,13 @@ __global__ __launch_bounds__(64) void l_pack_kernel(const float* __restrict__ L,
 // the next odd one its helper -- whatever set of workgroups is resident, all but at most 8 tiles have their helper resident too,
 // and those finish without waiting for anybody, so a helper that starts late only delays.  The tile never depends on it either: a chain
 // wave that waits longer than DUO_TIMEOUT for accumulators computes the whole chain itself from then on (same bits).
+// Launches with at most a third as many tiles as CUs ("trio") give a tile TWO helpers: the second takes the farthest half of
+// the helpers' share and hands its accumulators to the first, which continues and hands over to the tile -- a pipeline of three
+// CUs per chain; the tile's own share (trio_pol) is then small enough for its column steps to set the pace to the last panel.
 constexpr int DUO_MAX_TILES = 128;            // tiles with a helper (scratch is sized for them)
-constexpr int DUO_CTRL_WORDS = 8 + DUO_MAX_TILES * 5;  // 8 ticket counters, then {solved, ready[4]} per tile
+constexpr int DUO_TRIO_TILES = 80;            // ... with two helpers each (a third of the chip)
+constexpr int DUO_TW = 9;                     // flag words per tile: solved, ready[4] (helper -> tile), ready2[4] (second helper -> first)
+constexpr int DUO_CTRL_WORDS = 8 + DUO_MAX_TILES * DUO_TW;  // 8 ticket counters, then the tiles' flags
 constexpr unsigned long long DUO_TIMEOUT = 20ull * 1000 * 1000;  // s_memtime ticks (0.2 s at 100 MHz)
 // number of source panels the tile's own waves keep, of the c = s - 1 panels of step s's chain (the nearest ones);
 // pol = xa | xb << 8 | xmin << 16 | cmin << 24:  x = max(xmin, xa c / 64 - xb) from c >= cmin on, everything below
@@ -589,7 +594,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                                                       float* __restrict__ ErrT, int pbase, const int* __restrict__ rowlist,
                                                       const int* __restrict__ nactive, int opt_fast,
                                                       uint32_t* __restrict__ ctrl, float* __restrict__ Facc,
-                                                      float* __restrict__ ErrH, uint32_t tag, int duo_pol, int ncu) {
+                                                      float* __restrict__ ErrH, uint32_t tag, int duo_pol, int ncu, int trio_pol,
+                                                      int64_t facc_stride, int64_t errh_stride) {
     __shared__ float4 Ld[SPLIT ? 1 : 2][SPLIT ? 1 : SB][16];  // panel triangle of L, [jj][c16][k] <-> L[j0+jj][j0 + c16 + 16k]
     __shared__ __align__(16) float Ld4[SPLIT ? 2 * SB * SB : 4];  // split layout: [buf][jj][sub][k] <-> L[j0+jj][j0 + sub + 4k]
     __shared__ float Fs[SPLIT ? 3 : 1][SPLIT ? 16 : 1][16];    // split layout: sorted codebook, lo, hi of the 16 rows (set-up -> P wave)
@@ -615,10 +621,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     const int nact = nactive ? *nactive : m;
     int tile = blockIdx.x;
     bool duo = false, helper = false;
+    int hstage = 0, nhelp = 1;  // this workgroup: 0 the tile, 1 / 2 its first / second helper; helpers per tile
+    int pol = duo_pol;          // the split policy in force
     if constexpr (!SPLIT) {
         if (duo_pol != 0 && GANQ_SOLVE_PRIME == 0) {
             const int A = (min(nact, m) + SR - 1) / SR;  // active tiles
             duo = A <= DUO_MAX_TILES && 16 * ((A + 7) >> 3) <= min((int)gridDim.x, ncu);
+            if (trio_pol != 0 && A <= DUO_TRIO_TILES && 24 * ((A + 7) >> 3) <= min((int)gridDim.x, ncu)) {
+                duo = true;
+                nhelp = 2;
+                pol = trio_pol;
+            }
             if (duo) {  // roles by ticket (see above); a launch without helpers keeps tile = blockIdx and draws nothing
                 // one counter per residue class of blockIdx mod 8 (an XCD, when workgroups are dealt round-robin): 256 draws on one
                 // address serialise for tens of microseconds, and a pair drawn from one class shares an L2
@@ -633,8 +646,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                 }
                 __syncthreads();
                 const int tk = (int)s_tk;
-                tile = cls + 8 * (tk >> 1);
-                helper = (tk & 1) != 0;
+                tile = cls + 8 * (tk / (nhelp + 1));
+                hstage = tk % (nhelp + 1);
+                helper = hstage != 0;
             }
         }
     }
@@ -1041,7 +1055,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
             GANQ_TRACE(0, s, 3);
             // (the barrier waited for every wave's stores: the panel's block is in memory before the helper hears of it)
-            if (duo && tid == 0 && s >= 1) __hip_atomic_store(&ctrl[8 + 5 * tile], tag | (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (duo && tid == 0 && s >= 1) __hip_atomic_store(&ctrl[8 + DUO_TW * tile], tag | (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
             GANQ_TRACE(0, s, 4);
         }
@@ -1061,7 +1075,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     // shared by both roles (the P waves run a chain too when they assist, see below)
     const __amdgpu_buffer_rsrc_t rsrcL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0xffffffff, 0x00020000);
     // (a helper workgroup reads its own copy of the tile's Err blocks, see below)
-    float* __restrict__ errg = helper ? ErrH + (int64_t)tile * nb * SBLK : errt;
+    float* __restrict__ errg = helper ? ErrH + (hstage - 1) * errh_stride + (int64_t)tile * nb * SBLK : errt;
     const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(errg, 0, 0xffffffff, 0x00020000);
     // zero records: every load through it is out of range and returns 0
     const __amdgpu_buffer_rsrc_t rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lr), 0, 0, 0x00020000);
@@ -1169,24 +1183,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     if (helper) {
         if constexpr (!SPLIT) {
             const __amdgpu_buffer_rsrc_t rsrcM = __builtin_amdgcn_make_buffer_rsrc(errt, 0, 0xffffffff, 0x00020000);  // the tile's blocks
-            const __amdgpu_buffer_rsrc_t rsrcF =
-                __builtin_amdgcn_make_buffer_rsrc(Facc + (int64_t)tile * (nb + 1) * SBLK, 0, 0xffffffff, 0x00020000);
-            const uint32_t* solved = ctrl + 8 + 5 * tile;
-            uint32_t* ready = ctrl + 8 + 5 * tile + 1 + gw;
+            // accumulators: out to the next stage (the tile, or the first helper), in from the second helper (first helper of a trio)
+            const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(
+                Facc + (hstage - 1) * facc_stride + (int64_t)tile * (nb + 1) * SBLK, 0, 0xffffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsrcU =
+                __builtin_amdgcn_make_buffer_rsrc(Facc + facc_stride + (int64_t)tile * (nb + 1) * SBLK, 0, 0xffffffff, 0x00020000);
+            const uint32_t* solved = ctrl + 8 + DUO_TW * tile;
+            uint32_t* ready = ctrl + 8 + DUO_TW * tile + 1 + 4 * (hstage - 1) + gw;
+            const uint32_t* upstream = ctrl + 8 + DUO_TW * tile + 5 + gw;
             int have = nb;  // lowest panel copied so far
             for (int s = 1; s <= nb - 1; ++s) {
                 const int c = s - 1;
-                const int h = c - duo_near(c, duo_pol);  // source panels nb-1 .. nb-h are this workgroup's
+                const int h = c - duo_near(c, pol);  // source panels nb-1 .. nb-h are the helpers'
                 if (h <= 0) continue;
-                const int need = nb - h;
+                const int h2 = nhelp == 2 ? h / 2 : 0;                    // ... nb-1 .. nb-h2 the second helper's
+                const int phi = hstage == 2 || h2 == 0 ? nb - 1 : nb - 1 - h2;  // this workgroup's panels: phi .. need
+                const int need = hstage == 2 ? nb - h2 : nb - h;
+                if (phi < need) continue;  // (second helper of a trio at a step whose share is a single panel)
                 if (need < have) {  // (uniform over the four waves)
-                    // panel p was solved in step nb - p: wait until the tile has announced step h
+                    // panel p was solved in step nb - p: wait until the tile has announced that step
                     int seen = 0;
                     if (lane == 0) {
                         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
                         for (;;) {
                             const uint32_t v = __hip_atomic_load(solved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)h) {
+                            if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)(nb - need)) {
                                 seen = 1;
                                 break;
                             }
@@ -1208,10 +1229,27 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                     __syncthreads();
                 }
                 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (hstage == 1 && h2 > 0) {  // first helper of a trio: continue from the second helper's accumulators
+                    int ok = 0;
+                    if (lane == 0) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                        for (;;) {
+                            const uint32_t v = __hip_atomic_load(upstream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)s) {
+                                ok = 1;
+                                break;
+                            }
+                            if (__builtin_amdgcn_s_memtime() - t0 > 16 * DUO_TIMEOUT) break;
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                    }
+                    if (!__builtin_amdgcn_readfirstlane(ok)) return;  // (the tile gives up on this wave's accumulators and works alone)
+                    acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcU, voff + 1024 * gw, s * SBLKB, 16));
+                }
                 const int ct = SKR * (nb - 1 - s) + gw;  // this wave's 16-wide tile of panel bG = nb - 1 - s
                 const int plds = max(need, pbase);
-                chain(std::integral_constant<int, 1>{}, nb - 1, plds, ct, false);
-                chain(std::integral_constant<int, 0>{}, min(nb - 1, plds - 1), need, ct, false);
+                chain(std::integral_constant<int, 1>{}, phi, plds, ct, false);
+                chain(std::integral_constant<int, 0>{}, min(phi, plds - 1), need, ct, false);
 #if GANQ_MFMA_INPLACE
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #endif
@@ -1261,11 +1299,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
             int top = nb - 1;
             if constexpr (!SPLIT) {
                 if (duo_live) {
-                    const int c = s - 1, h = c - duo_near(c, duo_pol);
+                    const int c = s - 1, h = c - duo_near(c, pol);
                     if (h > 0) {
                         int ok = 0;
                         if (lane == 0) {
-                            const uint32_t* ready = ctrl + 8 + 5 * tile + 1 + gw;
+                            const uint32_t* ready = ctrl + 8 + DUO_TW * tile + 1 + gw;
                             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
                             for (;;) {
                                 const uint32_t v = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1381,8 +1419,8 @@ static SolveLayout solve_layout(int64_t m, int64_t n) {
     lo.lr_bytes = align_up((size_t)lo.nb * (size_t)lo.NT * SBLKB, 256);
     // helper workgroups (SB == 64 only): accumulators per (tile, step), the helpers' own copy of the Err blocks, flags
     const size_t dt = SPLIT ? 0 : (size_t)std::min<int64_t>(tiles, DUO_MAX_TILES);
-    lo.facc_bytes = align_up(dt * (size_t)(lo.nb + 1) * SBLKB, 256);
-    lo.errh_bytes = align_up(dt * (size_t)lo.nb * SBLKB, 256);
+    lo.facc_bytes = 2 * align_up(dt * (size_t)(lo.nb + 1) * SBLKB, 256);  // (x 2: one set per helper of a tile)
+    lo.errh_bytes = 2 * align_up(dt * (size_t)lo.nb * SBLKB, 256);
     lo.ctrl_bytes = align_up((size_t)DUO_CTRL_WORDS * sizeof(uint32_t), 256);
     lo.total = lo.errt_bytes + lo.lr_bytes + lo.facc_bytes + lo.errh_bytes + lo.ctrl_bytes;
     return lo;
@@ -1453,7 +1491,8 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
         return v;
     }();
-    int duo_pol = 0, grid = tiles;
+    int duo_pol = 0, trio_pol = 0, grid = tiles;
+    const int64_t facc_stride = (int64_t)(lo.facc_bytes / 2 / sizeof(float)), errh_stride = (int64_t)(lo.errh_bytes / 2 / sizeof(float));
     if (!SPLIT && opt_get(OPT_SOLVE_DUO) != 0 && ncu >= 16 && lo.nb <= 1000) {
         const int xa = (int)opt_get(OPT_SOLVE_DUO_XA), xb = (int)opt_get(OPT_SOLVE_DUO_XB), xmin = (int)opt_get(OPT_SOLVE_DUO_XMIN),
                   cmin = (int)opt_get(OPT_SOLVE_DUO_CMIN);
@@ -1461,6 +1500,12 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
         if (lo.nb - 2 >= std::max(cmin, 1)) {  // some chain is long enough to be shared
             duo_pol = opt_get(OPT_SOLVE_DUO) == 2 ? (int)((unsigned)pol | 0x80000000u) : pol;  // 2 (tests): mute helpers, see the kernel
             grid = std::max(tiles, std::min(16 * ((tiles + 7) / 8), ncu / 16 * 16));
+            // two helpers per tile where a third of the chip holds the tiles: its own split policy (the tile keeps less)
+            if (opt_get(OPT_SOLVE_TRIO) != 0 && ncu >= 24) {
+                const int xa3 = (int)opt_get(OPT_SOLVE_TRIO_XA), xb3 = (int)opt_get(OPT_SOLVE_TRIO_XB);
+                trio_pol = (xa3 & 255) | ((xb3 & 255) << 8) | ((std::max(xmin, 1) & 255) << 16) | ((std::max(cmin, 1) & 127) << 24);
+                grid = std::max(grid, std::min(24 * ((tiles + 7) / 8), ncu / 24 * 24));
+            }
         }
     }
     static std::atomic<uint32_t> epoch{0};
@@ -1472,10 +1517,10 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
     if (SOLVE_PF && tiles <= 256 && n > 4096) fast |= 2;
     if (mfma_k_ascending()) {
         hipLaunchKernelGGL(solve_s_kernel<true>, dim3(grid), dim3(SOLVE_THREADS), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
-                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast, ctrl, facc, errh, tag, duo_pol, ncu);
+                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast, ctrl, facc, errh, tag, duo_pol, ncu, trio_pol, facc_stride, errh_stride);
     } else {
         hipLaunchKernelGGL(solve_s_kernel<false>, dim3(grid), dim3(SOLVE_THREADS), smem, stream, W, L, ldl, Lr, lo.NT, T, (int)m, (int)n,
-                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast, ctrl, facc, errh, tag, duo_pol, ncu);
+                           V, Q_out, Err_out, errt, pbase, rowlist, nactive, fast, ctrl, facc, errh, tag, duo_pol, ncu, trio_pol, facc_stride, errh_stride);
     }
     GANQ_LAUNCH_CHECK();
     return 0;

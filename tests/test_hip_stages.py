@@ -164,12 +164,16 @@ def test_solve_s_helper_workgroups_bit_identical(hip, oracle, m, n, V, seed, lib
     Wd, Ld, Td = dev(W), dev(L), dev(T0)
     lib_options(GANQ_SOLVE_DUO=0)
     Q0, E0 = hip.solve_s(Wd, Ld, Td, want_err=True)
-    runs = [dict(GANQ_SOLVE_DUO=1), dict(GANQ_SOLVE_DUO=2),
+    runs = [dict(GANQ_SOLVE_DUO=1), dict(GANQ_SOLVE_DUO=2), dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_TRIO=0),
+            # two helpers per tile (launches with at most a third as many tiles as CUs): the tile keeps nearly nothing / nearly all
+            dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_TRIO=1, GANQ_SOLVE_TRIO_XA=0, GANQ_SOLVE_TRIO_XB=0),
+            dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_TRIO=1, GANQ_SOLVE_TRIO_XA=56, GANQ_SOLVE_TRIO_XB=2),
+            dict(GANQ_SOLVE_DUO=2, GANQ_SOLVE_TRIO=1, GANQ_SOLVE_TRIO_XA=26, GANQ_SOLVE_TRIO_XB=8),
             dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_DUO_XA=0, GANQ_SOLVE_DUO_XB=0, GANQ_SOLVE_DUO_XMIN=1, GANQ_SOLVE_DUO_CMIN=1),   # all but one panel far
             dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_DUO_XA=60, GANQ_SOLVE_DUO_XB=0, GANQ_SOLVE_DUO_XMIN=1, GANQ_SOLVE_DUO_CMIN=3),  # nearly all near
             dict(GANQ_SOLVE_DUO=1, GANQ_SOLVE_DUO_XA=20, GANQ_SOLVE_DUO_XB=5, GANQ_SOLVE_DUO_XMIN=3, GANQ_SOLVE_DUO_CMIN=12)]
     for opts in runs:
-        lib_options(**opts)
+        lib_options(reset=("GANQ_SOLVE_TRIO", "GANQ_SOLVE_TRIO_XA", "GANQ_SOLVE_TRIO_XB"), **opts)
         for _ in range(2):  # twice: the flags of the first launch must not satisfy the second
             Q1, E1 = hip.solve_s(Wd, Ld, Td, want_err=True)
             assert torch.equal(Q0, Q1), f"{opts}: {(Q0 != Q1).sum().item()} indices differ from the single-workgroup solve"
