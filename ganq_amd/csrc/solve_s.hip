@@ -699,20 +699,44 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
     }
     const int gtid = gw * 64 + lane;  // thread index inside the role
     if (SOLVE_PF && wv == 8) {
-        if (!(opt_fast & 2) || helper) return;  // not asked for: gone before the first barrier
-        // Prefetch wave.  Every workgroup walks the packed L in the same order at about the same pace, and every block is
-        // read exactly once per workgroup: the first of the 32 workgroups behind one L2 to ask for a block waits for HBM
-        // (the 67 MB do not stay in the Infinity Cache between launches), and the others, in step with it, wait along --
-        // the chain ran at the latency of that miss, not at the rate of the matrix cores.  This wave touches, one step
-        // ahead, the lines the chain waves of its XCD will read in the next step (a tile's blocks are contiguous in the
-        // tile-major layout; the workgroups of an XCD share the lines out among themselves), and does nothing else.
+        if (helper) return;  // (a helper workgroup is four chain waves)
+        // The ninth wave.  (a) It carries every solved panel to memory (late round 3): the packed Err block from ErrPk to the tile's
+        // scratch -- where the chain waves or the helper workgroups read it -- and the indices from Qst to Q, 16 bytes per lane,
+        // between the two barriers of a step.  The column-step waves used to store both themselves, and since loads and stores
+        // share one counter their wait for the next panel's weights also waited for the stores just issued: 0.8 us of every panel
+        // step, on the critical path of the launch.  Now those waves issue no stores at all (stage API with an Err output aside),
+        // and this wave, which nobody waits for, sees its own stores acknowledged at the top of the next step and then tells
+        // the helper workgroups.
+        // (b) Prefetch, where asked for (bit 1 of opt_fast).  Every workgroup walks the packed L in the same order at about the
+        // same pace, and every block is read exactly once per workgroup: the first of the 32 workgroups behind one L2 to ask for
+        // a block waits for HBM (the 67 MB do not stay in the Infinity Cache between launches), and the others, in step with it,
+        // wait along -- the chain ran at the latency of that miss, not at the rate of the matrix cores.  This wave touches, one
+        // step ahead, the lines the chain waves of its XCD will read in the next step (a tile's blocks are contiguous in the
+        // tile-major layout; the workgroups of an XCD share the lines out among themselves).
+        const bool pf = (opt_fast & 2) != 0;
         const int nb_ = (n + SB - 1) / SB;
         const int nwg = (min(nact, m) + SR - 1) / SR;   // tiles that run
         const int xi = tile >> 3, nx = (nwg + 7) >> 3;  // this tile among those of its XCD (blockIdx % 8)
+        float* __restrict__ errt_ = ErrT + (int64_t)tile * nb_ * SBLK;
+        const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(errt_, 0, 0xffffffff, 0x00020000);
+        // indices: lane = (row of the tile, 16-column piece of the panel)
+        const int qrow = lane >> 2, qpiece = lane & 3;
+        const int qslot = tile * SR + qrow;
+        const bool qrow_ok = qslot < nact;
+        const int qprow = rowlist ? rowlist[min(qslot, nact - 1)] : min(qslot, m - 1);
+        uint8_t* __restrict__ qdst = Q + (int64_t)qprow * n + 16 * qpiece;
+        const bool q16 = (n & 15) == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0;  // 16-byte stores possible
         float sink = 0.0f;
         for (int s_ = 0; s_ <= nb_; ++s_) {
+            if (s_ >= 2) {
+                // the stores of the step before are acknowledged before this step's first barrier: the chain waves read that block
+                // from the scratch after it at the earliest, and the helpers may hear of it now
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (duo && lane == 0)
+                    __hip_atomic_store(&ctrl[8 + DUO_TW * tile], tag | (uint32_t)(s_ - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             const int bn = nb_ - 2 - s_;  // the panel whose chain runs in the NEXT step
-            if (bn >= 0 && bn + 1 <= nb_ - 1) {
+            if (pf && bn >= 0 && bn + 1 <= nb_ - 1) {
                 const int64_t lines = (int64_t)(nb_ - 1 - bn) * (SBLKB / 128);  // 128-byte lines per tile
                 const int64_t per = (lines + nx - 1) / nx, l0 = (int64_t)xi * per, l1 = min(lines, l0 + per);
 #pragma unroll
@@ -721,8 +745,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                     for (int64_t l = l0 + lane; l < l1; l += 64) sink += base[l * 32];
                 }
             }
-            __syncthreads();
-            __syncthreads();
+            __syncthreads();  // panel bP solved: its packed Err block (ErrPk) and its indices (Qst) are in LDS
+            const int bP = nb_ - s_;
+            if (bP <= nb_ - 1) {
+                const int j0 = bP * SB, wd = min(SB, n - j0);
+                if (duo || bP < pbase) {  // (blocks >= pbase live in LDS; only helper workgroups want them from memory)
+#pragma unroll
+                    for (int q4 = 0; q4 < SKR; ++q4) {
+                        const u32x4raw v = __builtin_bit_cast(u32x4raw, *reinterpret_cast<const f32x4v*>(ErrPk + (q4 * 64 + lane) * 4));
+                        if (duo) __builtin_amdgcn_raw_buffer_store_b128(v, rsT, (q4 * 64 + lane) * 16, bP * SBLKB, 16);  // sc1: for another CU
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, rsT, (q4 * 64 + lane) * 16, bP * SBLKB, 0);
+                    }
+                }
+                if (qrow_ok && 16 * qpiece < wd) {
+                    uint4 qv = *reinterpret_cast<const uint4*>(&Qst[0][0][0] + qrow * SB + 16 * qpiece);
+                    if (q16 && 16 * qpiece + 16 <= wd) {
+                        *reinterpret_cast<uint4*>(qdst + j0) = qv;
+                    } else {
+                        const uint32_t w4[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (16 * qpiece + e < wd) qdst[j0 + e] = (uint8_t)((w4[e >> 2] >> (8 * (e & 3))) & 0xffu);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS reads done (ErrPk / Qst are free again); stores in flight
         }
         if (sink == 1.2345e-30f) ErrT[0] = sink;  // never true: keeps the loads
         return;
@@ -1002,7 +1049,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                         nsel += dpp_u<0x141>(nsel);
                         nsel += dpp_u<0x140>(nsel);
                         bad = __ballot(nsel != (uint32_t)wd) != 0ull;
-                        if (!bad) {
+                        if (!bad && (!SOLVE_PF || ErrOut)) {  // (the indices stay in Qst for the ninth wave otherwise)
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1035,11 +1082,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                         // the block lives in LDS (panels >= pbase, never read back from memory) or in the global scratch; with a
                         // helper workgroup every block also goes to the scratch, visible to the other CU
                         if (bP >= pbase) ErrL[(bP - pbase) * SBLK + pk_idx[k]] = ev;
-                        if (duo) __hip_atomic_store(&errt[bP * SBLK + pk_idx[k]], ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        else if (bP < pbase) errt[bP * SBLK + pk_idx[k]] = ev;
-                        if (col < wd && prow_ok) {
-                            Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
-                            if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
+                        if constexpr (SOLVE_PF) {
+                            // the ninth wave takes the block and the indices to memory; a panel redone by the reductions has its
+                            // indices in registers: filed where the fast path files them
+#ifndef GANQ_SOLVE_NO_P
+                            if (bad) qstage[c16 + 16 * k] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
+#endif
+                            if (ErrOut && col < wd && prow_ok) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
+                        } else {
+                            if (duo) __hip_atomic_store(&errt[bP * SBLK + pk_idx[k]], ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else if (bP < pbase) errt[bP * SBLK + pk_idx[k]] = ev;
+                            if (col < wd && prow_ok) {
+                                Q[(int64_t)prow * n + j0 + col] = (uint8_t)min(st.q[k], (uint32_t)(V - 1));
+                                if (ErrOut) ErrOut[(int64_t)prow * n + j0 + col] = st.e[k];
+                            }
                         }
                     }
                 } else {
@@ -1051,11 +1107,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                     }
                 }
             GANQ_TRACE(0, s, 2);
-            if (duo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's Err stores are acknowledged
-            __syncthreads();  // panel bP solved (ErrPk, ErrT visible); part 1 of panel bG done
+            if (!SOLVE_PF && duo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's Err stores are acknowledged
+            __syncthreads();  // panel bP solved (ErrPk, Qst in LDS); part 1 of panel bG done
             GANQ_TRACE(0, s, 3);
-            // (the barrier waited for every wave's stores: the panel's block is in memory before the helper hears of it)
-            if (duo && tid == 0 && s >= 1) __hip_atomic_store(&ctrl[8 + DUO_TW * tile], tag | (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (without the ninth wave: the barrier waited for every wave's stores, the panel's block is in memory before the helper
+            // hears of it)
+            if (!SOLVE_PF && duo && tid == 0 && s >= 1)
+                __hip_atomic_store(&ctrl[8 + DUO_TW * tile], tag | (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();  // R of panel bG, its Ld / Dg ready; ErrPk free
             GANQ_TRACE(0, s, 4);
         }
