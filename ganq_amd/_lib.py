@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("GANQ_HIP_LIB") or os.path.join(_PKG_DIR, "libganq_hip
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 
 FLAG_ALIAS_Q = 1
+FLAG_NO_HELPERS = 2
 
 _c_i64 = ctypes.c_int64
 _c_vp = ctypes.c_void_p
@@ -32,7 +33,8 @@ SIGNATURES = {
     "ganq_hip_selftest": (ctypes.c_int, [_c_vp]),
     "ganq_debug_div_check": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _c_vp, _c_vp, _c_vp]),
     "ganq_debug_wh_product": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp]),
-    "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp]),
+    "ganq_hessian_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
     "ganq_cholesky_workspace_bytes": (_c_sz, [_c_i64]),
     "ganq_cholesky": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_prologue_rowstats": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp]),
@@ -298,7 +300,7 @@ def run_layer_workspace(m, n, V, device):
     return _workspace(lib().ganq_run_layer_workspace_bytes(m, n, V), device)
 
 
-def run_layer(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None):
+def run_layer(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None, helpers=True):
     """ganq.py:516-634.  -> (T_best [m,V], Q uint8 [m,n], dists float64 [K], best_k int32 0-dim); all on the GPU."""
     W, H, T0 = _dev_f32(W, "W"), _dev_f32(H, "H"), _dev_f32(T0, "T0")
     if not (L.is_cuda and L.dtype == torch.float32 and L.stride(1) == 1):
@@ -313,12 +315,12 @@ def run_layer(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None):
     best_k = torch.full((), -1, dtype=torch.int32, device=W.device)
     ws = workspace if workspace is not None else run_layer_workspace(m, n, V, W.device)
     _call("ganq_run_layer", (W, H, L, T0, T, Q, dists, best_k, ws), W.data_ptr(), H.data_ptr(), L.data_ptr(), L.stride(0), T0.data_ptr(), m, n, V, int(K),
-                                FLAG_ALIAS_Q if alias_q else 0, float(rcond), T.data_ptr(), Q.data_ptr(),
-                                dists.data_ptr(), best_k.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
+          (FLAG_ALIAS_Q if alias_q else 0) | (0 if helpers else FLAG_NO_HELPERS), float(rcond), T.data_ptr(), Q.data_ptr(),
+          dists.data_ptr(), best_k.data_ptr(), ws.data_ptr(), ws.numel(), _ST)
     return T, Q, dists[:K], best_k
 
 
-def run_layer_rows(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None, want_q_all=None):
+def run_layer_rows(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None, want_q_all=None, helpers=True):
     """ganq_run_layer_rows: the fused loop on a slice of a layer's rows with the per-iteration records the owner of the
     whole layer needs.  -> dict(T_all [K,m,V], loss_rows_all [K,m] fp64, Q_last [m,n] uint8 (indices of the last
     iteration), Q_all [K,m,n] or None, dists [K] / best_k / T_best of the slice alone)."""
@@ -344,7 +346,8 @@ def run_layer_rows(W, H, L, T0, K, alias_q=True, rcond=-1.0, workspace=None, wan
     # always run the aliasing variant inside the slice: Q then holds the LAST iteration's indices, which is what the
     # reference's torch branch returns; the per-iteration indices (if wanted) come back in Q_all
     _call("ganq_run_layer_rows", (W, H, L, T0, T, Q, dists, best_k, T_all, loss_all, Q_all, ws), W.data_ptr(), H.data_ptr(),
-          L.data_ptr(), L.stride(0), T0.data_ptr(), m, n, V, K, FLAG_ALIAS_Q, float(rcond), T.data_ptr(), Q.data_ptr(),
+          L.data_ptr(), L.stride(0), T0.data_ptr(), m, n, V, K, FLAG_ALIAS_Q | (0 if helpers else FLAG_NO_HELPERS), float(rcond),
+          T.data_ptr(), Q.data_ptr(),
           dists.data_ptr(), best_k.data_ptr(), T_all.data_ptr(), loss_all.data_ptr(), _ptr(Q_all), ws.data_ptr(), ws.numel(),
           _ST)
     return dict(T_all=T_all, loss_rows_all=loss_all, Q_last=Q, Q_all=Q_all, dists=dists[:K], best_k=best_k, T_best=T)
@@ -407,8 +410,13 @@ def hessian_accum(H, X, nsamples_before: int, batch: int):
     rows, n = X.shape
     if H.shape != (n, n):
         raise GanqHipError(f"shape mismatch H{tuple(H.shape)} X{tuple(X.shape)}")
-    _call("ganq_hessian_accum", (H, X), H.data_ptr(), X.data_ptr(), code, rows, n, int(nsamples_before), int(batch),
-                                    _ST)
+    # partial tiles of the token-split launches: torch-owned scratch on the current stream (the caching allocator
+    # re-uses it from call to call; nothing outlives the call on the library's side)
+    with torch.cuda.device(H.device):
+        nbytes = lib().ganq_hessian_workspace_bytes(rows, n)
+    ws = _workspace(nbytes, H.device) if nbytes else None
+    _call("ganq_hessian_accum", (H, X, ws), H.data_ptr(), X.data_ptr(), code, rows, n, int(nsamples_before), int(batch),
+          ws.data_ptr() if ws is not None else None, int(nbytes), _ST)
     return H
 
 

@@ -85,6 +85,9 @@ long long opt_get(int id);
 // (recorded per (device, kernel) under a mutex)
 int ensure_dynamic_lds(const void* func, size_t bytes);
 
+// compute units of the CURRENT device (cached per device index; 0 on failure)
+int current_device_cus();
+
 // ---- optional per-kernel timing (profile.hip) ----
 enum KernelId : int {
     KID_SOLVE_S = 0,

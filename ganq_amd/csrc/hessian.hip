@@ -455,42 +455,8 @@ const uint32_t* tile_table(int tiles, int mh, int* count) {
     return dev;
 }
 
-// scratch of the token-split launches: partial tiles, one buffer per (device, stream) -- launches on one stream are ordered, two
-// streams never share a buffer
-struct SkScratch {
-    int device;
-    hipStream_t stream;
-    float* buf;
-    size_t bytes;
-};
-std::vector<SkScratch> g_sk_scratch;
-std::mutex g_sk_mu;
-float* sk_scratch(hipStream_t stream, size_t bytes) {
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_sk_mu);
-    for (SkScratch& t : g_sk_scratch)
-        if (t.device == device && t.stream == stream) {
-            if (t.bytes >= bytes) return t.buf;
-            return nullptr;  // (sized for the largest launch the first time: see below)
-        }
-    if (g_sk_scratch.size() >= 16) return nullptr;  // many streams: they use the whole-tile kernel
-    float* buf = nullptr;
-    if (hipMalloc(&buf, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    g_sk_scratch.push_back({device, stream, buf, bytes});
-    return buf;
-}
-int device_cus() {
-    static const int ncu = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-        return v;
-    }();
-    return ncu;
-}
+// scratch of the token-split launches (partial tiles): caller-owned, see ganq_hessian_workspace_bytes
+inline size_t sk_scratch_bytes(int ncu) { return (size_t)6 * (size_t)ncu * HT * HT * sizeof(float); }  // 6 ncu x 64 KB = 3 ncu x 128 KB (96 MB)
 }  // namespace
 
 #ifdef GANQ_HESS_TRACE
@@ -502,8 +468,15 @@ extern "C" int ganq_debug_hess_trace(unsigned long long* out8) {
 }
 #endif
 
+extern "C" size_t ganq_hessian_workspace_bytes(int64_t rows, int64_t n) {
+    // only staged groups (>= 128 slabs of tokens) on layers whose tiles are all on the fast path are ever cut
+    if (rows <= 0 || n <= 0 || (n % HT) != 0 || (rows + HK - 1) / HK < 128) return 0;
+    const int ncu = current_device_cus();
+    return ncu >= 8 ? sk_scratch_bytes(ncu) : 0;
+}
+
 extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
-                                  int64_t batch, void* stream_) {
+                                  int64_t batch, void* workspace, size_t workspace_bytes, void* stream_) {
     if (rows < 0 || n < 0 || nsamples_before < 0 || batch <= 0) return fail(-1, "ganq_hessian_accum: bad sizes");
     if (n == 0) return 0;
     if (dtype != 0 && dtype != 1) return fail(-2, "ganq_hessian_accum: dtype %d (0 = fp16, 1 = bf16)", dtype);
@@ -529,7 +502,7 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
     // workgroup slots (at least 32 slabs per part, at most 40 parts per tile: the fix-up reads a tile's parts one after the
     // other), and -- GANQ_HESS_WIDE -- the tiles are 256 x 128 where in_features allows.  Measured, 16384 tokens: see DESIGN.md.
     // A single sequence of 2048 tokens loses 10-30 % to a second launch and stays on the whole-tile kernel.
-    const int ncu = device_cus();
+    const int ncu = current_device_cus();
     const int64_t nslab = (rows + HK - 1) / HK;
     const bool sk_ok = rows > 0 && rows <= piece_max && (n % HT) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ncu >= 8 && nslab >= 128;
     auto launch_sk = [&](auto mh_tag, bool whole_only) -> int {  // 1: launched, 0: not applicable, < 0: error
@@ -555,7 +528,7 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
                 part_slabs = (int)(((nslab + parts - 1) / parts + 3) / 4 * 4);  // whole rounds of four slabs
                 parts = (int)((nslab + part_slabs - 1) / part_slabs);           // (no empty parts)
                 if ((int64_t)rest * parts <= (int64_t)6 * ncu / MH)             // what the scratch holds
-                    part = sk_scratch(stream, (size_t)6 * ncu * HT * HT * sizeof(float));  // 6 ncu x 64 KB = 3 ncu x 128 KB (96 MB)
+                    part = (workspace && workspace_bytes >= sk_scratch_bytes(ncu)) ? static_cast<float*>(workspace) : nullptr;
             }
             if (parts < 2 || !part) {
                 bulk = count;

@@ -193,7 +193,8 @@ static int run_layer_impl(const float* W, const float* H, const float* L, int64_
     const int* rowlist = nullptr;
     const int* nactive = nullptr;
     for (int k = 0; k < K; ++k) {
-        rc = solve_s_launch(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, stream, rowlist, nactive);
+        rc = solve_s_launch(W, L, ldl, Tc, m, n, V, Qwork, nullptr, ws + lo.off_solve, stream, rowlist, nactive,
+                            (flags & GANQ_FLAG_NO_HELPERS) == 0);
         if (rc) return rc;
         if (k == 0 && ps) GANQ_HIP_CHECK(hipStreamWaitEvent(stream, ps->join, 0));
         // new codebook and, from the same A and b, the loss of (new codebook, these indices)  (ganq.py:589-591, :621-622)

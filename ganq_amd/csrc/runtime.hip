@@ -92,6 +92,16 @@ int ensure_dynamic_lds(const void* func, size_t bytes) {
     return 0;
 }
 
+int current_device_cus() {
+    static std::atomic<int> cache[64];  // zero-initialised; 0 = not asked yet
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64 && (v = cache[dev].load(std::memory_order_relaxed)) > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+    if (dev >= 0 && dev < 64 && v > 0) cache[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+
 }  // namespace ganq
 
 using namespace ganq;

@@ -570,7 +570,11 @@ constexpr int DUO_MAX_TILES = 128;            // tiles with a helper (scratch is
 constexpr int DUO_TRIO_TILES = 80;            // ... with two helpers each (a third of the chip)
 constexpr int DUO_TW = 9;                     // flag words per tile: solved, ready[4] (helper -> tile), ready2[4] (second helper -> first)
 constexpr int DUO_CTRL_WORDS = 8 + DUO_MAX_TILES * DUO_TW;  // 8 ticket counters, then the tiles' flags
-constexpr unsigned long long DUO_TIMEOUT = 20ull * 1000 * 1000;  // s_memtime ticks (0.2 s at 100 MHz)
+// s_memtime ticks (100 MHz): 0.5 ms, about 60 column-panel steps (6-8 us each; 25 us for the last steps of n = 16384) -- long enough
+// for a helper that is resident but behind (it starts with a cold operand ring), short enough that a helper that is NOT resident
+// (another launch holds the CUs: side streams, a second process) costs a tile one wait of the order of the kernel's own time
+// instead of the 0.2 s of round 3.  The helpers' own waits are 16 x this.
+constexpr unsigned long long DUO_TIMEOUT = 50ull * 1000;
 // number of source panels the tile's own waves keep, of the c = s - 1 panels of step s's chain (the nearest ones);
 // pol = xa | xb << 8 | xmin << 16 | cmin << 24:  x = max(xmin, xa c / 64 - xb) from c >= cmin on, everything below
 __host__ __device__ __forceinline__ int duo_near(int c, int pol) {
@@ -1510,7 +1514,7 @@ int solve_s_pack_l(const float* L, int64_t ldl, int64_t m, int64_t n, void* work
 
 // the solve proper; the workspace already holds the packed L
 int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, int64_t m, int64_t n, int V, uint8_t* Q_out,
-                   float* Err_out, void* workspace, hipStream_t stream, const int* rowlist, const int* nactive) {
+                   float* Err_out, void* workspace, hipStream_t stream, const int* rowlist, const int* nactive, bool allow_helpers) {
     const SolveLayout lo = solve_layout(m, n);
     float* errt = static_cast<float*>(workspace);
     const float* Lr = reinterpret_cast<const float*>(static_cast<char*>(workspace) + lo.errt_bytes);
@@ -1544,14 +1548,10 @@ int solve_s_launch(const float* W, const float* L, int64_t ldl, const float* T, 
     float* facc = reinterpret_cast<float*>(wsb + lo.errt_bytes + lo.lr_bytes);
     float* errh = reinterpret_cast<float*>(wsb + lo.errt_bytes + lo.lr_bytes + lo.facc_bytes);
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(wsb + lo.errt_bytes + lo.lr_bytes + lo.facc_bytes + lo.errh_bytes);
-    static const int ncu = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-        return v;
-    }();
+    const int ncu = current_device_cus();
     int duo_pol = 0, trio_pol = 0, grid = tiles;
     const int64_t facc_stride = (int64_t)(lo.facc_bytes / 2 / sizeof(float)), errh_stride = (int64_t)(lo.errh_bytes / 2 / sizeof(float));
-    if (!SPLIT && opt_get(OPT_SOLVE_DUO) != 0 && ncu >= 16 && lo.nb <= 1000) {
+    if (!SPLIT && allow_helpers && opt_get(OPT_SOLVE_DUO) != 0 && ncu >= 16 && lo.nb <= 1000) {
         const int xa = (int)opt_get(OPT_SOLVE_DUO_XA), xb = (int)opt_get(OPT_SOLVE_DUO_XB), xmin = (int)opt_get(OPT_SOLVE_DUO_XMIN),
                   cmin = (int)opt_get(OPT_SOLVE_DUO_CMIN);
         const int pol = (xa & 255) | ((xb & 255) << 8) | ((std::max(xmin, 1) & 255) << 16) | ((std::max(cmin, 1) & 127) << 24);

@@ -184,14 +184,15 @@ def share_module_result(processor, named_module, owner: int, dist: Dist):
 class HipSolver:
     """the product path: every call goes to libganq_hip.so"""
 
-    def __init__(self):
+    def __init__(self, helpers: bool = True):
         from . import _lib
 
         self._lib = _lib
+        self.helpers = helpers  # False: the S-solve launches no helper workgroups (modules of a group run side by side)
 
     def run_layer_rows(self, W, H, L, T0, K, alias_q, rcond):
         """fused K-iteration loop on a row slice -> dict(T_all [K,m,V], loss_rows_all [K,m], Q_last, Q_all or None)"""
-        return self._lib.run_layer_rows(W, H, L, T0, K, alias_q=alias_q, rcond=rcond)
+        return self._lib.run_layer_rows(W, H, L, T0, K, alias_q=alias_q, rcond=rcond, helpers=self.helpers)
 
     def select_best(self, loss_rows_all):
         """[K, m] per-row losses of the whole layer -> (dists [K], best_k) in the single-GPU loop's summation order"""

@@ -145,6 +145,9 @@ class ModuleLooper:
                 threads.append(th)
                 th.start()
 
+        for n in todo:  # their S-solves share the CUs: no helper workgroups (solve_s.hip; the bits do not depend on it)
+            if hasattr(tasks[n], "solve_helpers"):
+                tasks[n].solve_helpers = False
         tasks[leaders[0]]._on_prologue_shared = start_followers
         try:
             self.processor.process(named[leaders[0]])

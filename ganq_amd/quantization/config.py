@@ -69,12 +69,6 @@ class QuantizeConfig:
     # not in the reference: False pairs the best codebook with its OWN indices instead of reproducing the
     # torch-branch aliasing of ganq.py:487,550,625-626 (see DESIGN.md "reference quirks")
     ganq_reference_q_alias: bool = field(default=True)
-    # not in the reference: "hip" factors the Hessian with ganq_cholesky and takes diag(Hinv) from ONE factorisation of
-    # the index-reversed matrix (the upper Cholesky factor U of H^-1 is P L'^-1 P with P H P = L' L'^T, so
-    # diag(U)[i] = 1 / L'[n-1-i][n-1-i]) instead of cholesky -> cholesky_inverse -> cholesky(upper);
-    # "torch" runs the reference's op sequence (gptq.py:280-309) on torch.linalg.  Both are fp32 backward-stable
-    # evaluations of the same quantities (they agree to ~1e-6 relative).
-    ganq_prologue: str = field(default="hip", metadata={"choices": ["hip", "torch"]})
     # not in the reference code (paper section 3.3 / Appendix A, "GANQ*"): fraction r of every weight row kept exactly
     # as sparse fp16 outliers (row-wise, beyond the 1 - r/2 and r/2 quantiles); GANQ quantizes the rest.  0 = off.
     ganq_outlier_ratio: float = field(default=0.0)

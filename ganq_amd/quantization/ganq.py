@@ -36,6 +36,9 @@ class GANQ(GPTQ):
         # set by the looper when torch.distributed runs this module's rows over several GPUs (SURVEY 8(e) axis 2): a
         # ganq_amd.distributed.Dist with world > 1.  Every rank must then call quantize() on the same statistics.
         self.row_dist = None
+        # cleared by the looper for the modules of a group it quantizes side by side on one GPU (streams): a helper workgroup
+        # of the S-solve may then not be resident with its tile (GANQ_FLAG_NO_HELPERS; same bits either way)
+        self.solve_helpers = True
 
     def _needs_only_hinv_diag(self) -> bool:
         return True
@@ -79,13 +82,14 @@ class GANQ(GPTQ):
             stats = {"timing": bool(getattr(self, "time_collectives", False))}
             T, Q, dists, best_k = gdist.run_layer_row_sharded(
                 W, self.Xxt_damped, self.L, None, self.iterations, alias_q=alias, dist=rd, stats=stats,
-                turn=getattr(self, "_collective_turn", None),
+                turn=getattr(self, "_collective_turn", None), solver=gdist.HipSolver(helpers=self.solve_helpers),
                 t0_fn=lambda W_rows: self._initialize_codebook_kmeans(W_rows, Hinv, num_bits, W.device))
             self.ganq_stats.update({k: v for k, v in stats.items() if k != "timing"})
         else:
             T0 = self._initialize_codebook_kmeans(W, Hinv, num_bits, W.device)
             assert T0.shape == (W.shape[0], V)
-            T, Q, dists, best_k = _lib.run_layer(W, self.Xxt_damped, self.L, T0, self.iterations, alias_q=alias)
+            T, Q, dists, best_k = _lib.run_layer(W, self.Xxt_damped, self.L, T0, self.iterations, alias_q=alias,
+                                                 helpers=self.solve_helpers)
         Wq, Losses = _lib.dequant_losses(W, T, Q, _hinv_diag(Hinv).contiguous())
         if sparse is not None:  # effective weight = dequantised dense part + the exact outliers
             rowptr, cols, vals = sparse

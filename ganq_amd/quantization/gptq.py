@@ -8,8 +8,9 @@ Host-side mirror of gptqmodel/quantization/gptq.py:42-393 with the same public s
   * everything lives on the GPU; there is no CPU fallback (the module must be on a cuda device);
   * GPTQ's own uniform-grid column loop (gptq.py:164-236) is NOT part of this path: only the GANQ subclass
     implements `_perform_quantization_loop`.
-With `ganq_prologue="hip"` (default) the prologue is three passes over the matrices (csrc/prologue.hip) and two in-place
-factorisations by csrc/cholesky.hip; `"torch"` keeps the reference's own op sequence on torch.linalg (A/B runs, tests).
+The prologue is three passes over the matrices (csrc/prologue.hip) and two in-place factorisations by csrc/cholesky.hip;
+there is no library-backed alternative in the product (the reference's own op sequence on torch.linalg lives in
+tests/oracle_quantizer.py as a checker).
 """
 import math
 import time
@@ -202,8 +203,7 @@ class GPTQ:
 
     def _prologue_key(self):
         c = self.qcfg
-        return (self.columns, c.act_sort, c.l_damp_style, c.damp_percent, c.damp_auto_increment, c.dead,
-                getattr(c, "ganq_prologue", "torch"), self._needs_only_hinv_diag())
+        return (self.columns, c.act_sort, c.l_damp_style, c.damp_percent, c.damp_auto_increment, c.dead)
 
     def _needs_only_hinv_diag(self) -> bool:
         """True when the quantization loop reads nothing of Hinv but its diagonal (GANQ does; see ganq.py)."""
@@ -287,52 +287,6 @@ class GPTQ:
         self.Xxt = None
         return W, dead, perm, invperm, Hinv, damp_percent
 
-    def _prologue_reference_ops(self, W, H):
-        """the reference's own op sequence (gptq.py:267-316) on torch -- `ganq_prologue="torch"`, and any quantizer that reads
-        more of Hinv than its diagonal"""
-        dead = torch.diag(H) == 0
-        H[dead, dead] = 1
-        if self.qcfg.dead == "zero":
-            W[:, dead] = 0
-        elif self.qcfg.dead == "mean":
-            W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
-        else:
-            assert False, f"Unknown dead mode: {self.qcfg.dead}"
-
-        perm = None
-        invperm = None
-        if self.qcfg.act_sort != "none":
-            assert self.qcfg.act_sort in ["asc", "desc"]
-            perm = torch.argsort(torch.diag(H), descending=self.qcfg.act_sort == "desc")
-            W = W[:, perm].contiguous()
-            H = H[perm][:, perm].contiguous()
-            invperm = torch.argsort(perm)
-
-        self.Xxt = H.clone()  # undamped
-        if self.qcfg.l_damp_style == "ganq":
-            offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
-            self.L = torch.linalg.cholesky(H + torch.diag(offset))
-
-        damp_percent = self.qcfg.damp_percent
-        Hinv = None
-        while 1 > damp_percent > 0:
-            try:
-                damp = damp_percent * torch.mean(torch.diag(H))
-                diag = torch.arange(self.columns, device=self.device)
-                H[diag, diag] += damp
-                self.Xxt_damped = H.clone()
-                L = torch.linalg.cholesky(H)
-                if self.qcfg.l_damp_style == "gptq":
-                    self.L = L.clone()
-                Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
-                break
-            except torch._C._LinAlgError as e:
-                if self.qcfg.damp_auto_increment != 0:
-                    damp_percent += self.qcfg.damp_auto_increment
-                else:
-                    raise e
-        return W, dead, perm, invperm, Hinv, damp_percent
-
     @torch.inference_mode()
     def quantize(self, blocksize=128):
         start = time.time()
@@ -354,15 +308,7 @@ class GPTQ:
         cached = getattr(self, "_leader_prologue", None)
         if cached is not None and cached["key"] == self._prologue_key():
             dead, perm, invperm = cached["dead"], cached["perm"], cached["invperm"]
-            if getattr(self.qcfg, "ganq_prologue", "torch") == "hip" and W.is_cuda:
-                W = _lib.prologue_weights(W, perm, dead, mean_fill=self.qcfg.dead == "mean")  # as the leader's own weights
-            else:
-                if self.qcfg.dead == "zero":
-                    W[:, dead] = 0
-                elif self.qcfg.dead == "mean":
-                    W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
-                if perm is not None:
-                    W = W[:, perm].contiguous()
+            W = _lib.prologue_weights(W, perm, dead, mean_fill=self.qcfg.dead == "mean")  # as the leader's own weights
             self.Xxt, self.L, self.Xxt_damped = cached["Xxt"], cached["L"], cached["Xxt_damped"]
             Hinv, damp_percent = cached["Hinv"], cached["damp_percent"]
             self.nsamples = cached["nsamples"]
@@ -371,11 +317,10 @@ class GPTQ:
                 raise RuntimeError("quantize(): this module follows a leader that has not been quantized (yet)")
             H = self.H
             del self.H
-            native = (getattr(self.qcfg, "ganq_prologue", "torch") == "hip" and self._needs_only_hinv_diag() and H.is_cuda)
-            if native:
-                W, dead, perm, invperm, Hinv, damp_percent = self._prologue_hip(W, H)
-            else:
-                W, dead, perm, invperm, Hinv, damp_percent = self._prologue_reference_ops(W, H)
+            if not self._needs_only_hinv_diag():
+                raise NotImplementedError("the HIP prologue yields diag(Hinv) only (all the GANQ loop reads of it, ganq.py:427-429,"
+                                          "637-638); a quantizer that needs the full inverse factor is outside this path")
+            W, dead, perm, invperm, Hinv, damp_percent = self._prologue_hip(W, H)
             if not (0 < damp_percent < 1):
                 raise ValueError(f"Quantization: `damp_percent` must between 0 and 1. current is {damp_percent}")
             followers = getattr(self, "_followers", [])

@@ -30,11 +30,13 @@
 extern "C" {
 #endif
 
-#define GANQ_HIP_ABI_VERSION 2
+#define GANQ_HIP_ABI_VERSION 3
 
 /* flags for ganq_run_layer */
 #define GANQ_FLAG_ALIAS_Q 1u /* reference torch-branch behaviour: indices of the LAST iteration are returned with \
                                 the codebook of the BEST one (ganq.py:487,550,625-626) */
+#define GANQ_FLAG_NO_HELPERS 2u /* the S-solve launches no helper workgroups: for callers that run several layers side by \
+                                   side on one device (streams), where a helper may not be resident with its tile */
 
 int ganq_hip_version(void);
 const char* ganq_hip_last_error(void);
@@ -57,9 +59,13 @@ int ganq_debug_wh_product(const float* W, const float* H, int64_t m, int64_t n, 
 /* ---- a1: Hessian accumulation (gptq.py:96-131 process_batch) --------------------------------
  * One calibration batch: X [rows, n] fp16 or bf16 (dtype: 0 = fp16, 1 = bf16), `batch` = number
  * of sequences in it (gptq.py:104), nsamples_before = sequences accumulated so far.
- *     H <- H * N/(N+batch) + (2/(N+batch)) * X^T X          H [n,n] fp32, updated in place       */
+ *     H <- H * N/(N+batch) + (2/(N+batch)) * X^T X          H [n,n] fp32, updated in place
+ * workspace: ganq_hessian_workspace_bytes() of caller-owned device scratch (partial tiles of the token-split launches
+ * of staged groups; borrowed for the call, nothing is retained).  NULL / too small is allowed: the call then uses the
+ * whole-tile kernel only (same H up to fp32 summation order).                                                   */
+size_t ganq_hessian_workspace_bytes(int64_t rows, int64_t n);
 int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
-                       int64_t batch, void* stream);
+                       int64_t batch, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- a2: prologue (gptq.py:280-309) -- lower Cholesky factor A = L L^T in fp32, in place (row-major, leading
  * dimension lda; the strictly upper triangle is zeroed like torch.linalg.cholesky does).  *info (device int32) is 0

@@ -68,45 +68,111 @@ void ganq_oracle_set_num_threads(int t) {
  * W [m,n], L [n,n] row-major lower-triangular (L[u*ldl + c]), T [m,V].
  * Q out [m,n] uint8; Err out [m,n] fp32 or NULL.
  * ------------------------------------------------------------------------------------------ */
+/* Speed (round 4; the bits are those of the plain loop it replaces): SS_R rows share every load of a row of L, and the
+ * update of the residual accumulators -- independent fmaf chains, one per (row, column) -- is a SIMD loop.  fmaf() is
+ * exactly rounded whether libm computes it or a vfmadd instruction does, so the two builds of the body (AVX2 + FMA when
+ * the CPU has them, baseline otherwise; chosen at run time) give the same indices and errors. */
+#define SS_R 8
+
+static inline __attribute__((always_inline)) void solve_rows_body(const float* W, const float* L, int64_t ldl, const float* T,
+                                                                  int64_t n, int V, int64_t i0, int R, uint8_t* Q, float* Err,
+                                                                  float* racc /* [SS_R][n] */) {
+    float err[SS_R];
+    for (int r = 0; r < R; ++r)
+        for (int64_t c = 0; c < n; ++c) racc[(size_t)r * n + c] = 0.0f;
+    for (int64_t j = n - 1; j >= 0; --j) {
+        const float* lrow = L + j * ldl;
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = i0 + r;
+            const float* w = W + i * n;
+            const float* t = T + i * V;
+            float q = racc[(size_t)r * n + j] / lrow[j];
+            float eff = w[j] + q;
+            float best = INFINITY;
+            int idx = 0, have_nan = 0;
+            for (int s = 0; s < V; ++s) {  /* torch.argmin (ganq.py:547): the first NaN wins, else the first minimum */
+                float d = fabsf(eff - t[s]);
+                if (d != d) {
+                    if (!have_nan) {
+                        have_nan = 1;
+                        idx = s;
+                    }
+                } else if (!have_nan && d < best) {
+                    best = d;
+                    idx = s;
+                }
+            }
+            err[r] = w[j] - t[idx];
+            Q[i * n + j] = (uint8_t)idx;
+            if (Err) Err[i * n + j] = err[r];
+        }
+        for (int r = 0; r < R; ++r) {
+            float* ra = racc + (size_t)r * n;
+            const float e = err[r];
+#pragma omp simd
+            for (int64_t c = 0; c < j; ++c) ra[c] = fmaf(e, lrow[c], ra[c]);
+        }
+    }
+}
+
+__attribute__((target("avx2,fma"))) static void solve_rows_fma(const float* W, const float* L, int64_t ldl, const float* T, int64_t n,
+                                                               int V, int64_t i0, int R, uint8_t* Q, float* Err, float* racc) {
+    solve_rows_body(W, L, ldl, T, n, V, i0, R, Q, Err, racc);
+}
+
+static void solve_rows_base(const float* W, const float* L, int64_t ldl, const float* T, int64_t n, int V, int64_t i0, int R,
+                            uint8_t* Q, float* Err, float* racc) {
+    solve_rows_body(W, L, ldl, T, n, V, i0, R, Q, Err, racc);
+}
+
+static int cpu_has_fma(void) {
+    static int known = -1;
+    if (known < 0) {
+        __builtin_cpu_init();
+        known = (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? 1 : 0;
+    }
+    return known;
+}
+
+/* fp64 accumulation of fp32 vectors, element by element (no reduction: the order of additions INTO an element is the
+ * caller's loop order); an AVX2 build of the same statements where the CPU has it -- no FMA flag, so still one rounded
+ * product and one rounded sum per element (-ffp-contract=off besides) */
+static inline __attribute__((always_inline)) void axpy_body(double* acc, const float* x, double a, int64_t n) {
+#pragma omp simd
+    for (int64_t v = 0; v < n; ++v) acc[v] += a * (double)x[v];
+}
+static inline __attribute__((always_inline)) void addw_body(double* acc, const float* x, int64_t n) {
+#pragma omp simd
+    for (int64_t v = 0; v < n; ++v) acc[v] += (double)x[v];
+}
+__attribute__((target("avx2"))) static void axpy_avx2(double* acc, const float* x, double a, int64_t n) { axpy_body(acc, x, a, n); }
+__attribute__((target("avx2"))) static void addw_avx2(double* acc, const float* x, int64_t n) { addw_body(acc, x, n); }
+static void axpy_base(double* acc, const float* x, double a, int64_t n) { axpy_body(acc, x, a, n); }
+static void addw_base(double* acc, const float* x, int64_t n) { addw_body(acc, x, n); }
+typedef void (*axpy_fn)(double*, const float*, double, int64_t);
+typedef void (*addw_fn)(double*, const float*, int64_t);
+static axpy_fn pick_axpy(void) { return cpu_has_fma() ? axpy_avx2 : axpy_base; }
+static addw_fn pick_addw(void) { return cpu_has_fma() ? addw_avx2 : addw_base; }
+
 int ganq_oracle_solve_s(const float* W, const float* L, int64_t ldl, const float* T, int64_t m, int64_t n,
                         int V, uint8_t* Q, float* Err) {
     if (V < 1 || V > GANQ_MAX_V || m < 0 || n < 0) return -1;
     int fail = 0;
+    const int use_fma = cpu_has_fma();
+    const int64_t blocks = (m + SS_R - 1) / SS_R;
 #pragma omp parallel
     {
-        float* racc = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+        float* racc = (float*)malloc(sizeof(float) * SS_R * (size_t)(n > 0 ? n : 1));
         if (!racc) {
 #pragma omp atomic write
             fail = 1;
         } else {
-#pragma omp for schedule(dynamic, 4)
-            for (int64_t i = 0; i < m; ++i) {
-                const float* w = W + i * n;
-                const float* t = T + i * V;
-                for (int64_t c = 0; c < n; ++c) racc[c] = 0.0f;
-                for (int64_t j = n - 1; j >= 0; --j) {
-                    const float* lrow = L + j * ldl;
-                    float q = racc[j] / lrow[j];
-                    float eff = w[j] + q;
-                    float best = INFINITY;
-                    int idx = 0, have_nan = 0;
-                    for (int s = 0; s < V; ++s) {  /* torch.argmin (ganq.py:547): the first NaN wins, else the first minimum */
-                        float d = fabsf(eff - t[s]);
-                        if (d != d) {
-                            if (!have_nan) {
-                                have_nan = 1;
-                                idx = s;
-                            }
-                        } else if (!have_nan && d < best) {
-                            best = d;
-                            idx = s;
-                        }
-                    }
-                    float err = w[j] - t[idx];
-                    Q[i * n + j] = (uint8_t)idx;
-                    if (Err) Err[i * n + j] = err;
-                    for (int64_t c = 0; c < j; ++c) racc[c] = fmaf(err, lrow[c], racc[c]);
-                }
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t blk = 0; blk < blocks; ++blk) {
+                const int64_t i0 = blk * SS_R;
+                const int R = (int)((m - i0) < SS_R ? (m - i0) : SS_R);
+                if (use_fma) solve_rows_fma(W, L, ldl, T, n, V, i0, R, Q, Err, racc);
+                else solve_rows_base(W, L, ldl, T, n, V, i0, R, Q, Err, racc);
             }
             free(racc);
         }
@@ -185,58 +251,78 @@ static void minnorm_solve(double* A, const double* b, int V, double rcond, doubl
  * rcond < 0 selects the reference default eps_fp32 * V.
  * Optional outputs A_out [m,V,V], b_out [m,V] (fp32) for stage-wise checks.
  * ------------------------------------------------------------------------------------------ */
+/* Speed (round 4): UT_R rows share every load of H, column strip by column strip of UT_W columns, so that the rows' partial
+ * sums G stay in cache.  Every element keeps its own order of additions -- G[a][v] over ascending u, then A[a][b] over
+ * ascending v -- so the sums are the bits of the plain row-at-a-time loops. */
+#define UT_R 8
+#define UT_W 512
 int ganq_oracle_update_t(const float* WH, const float* H, const uint8_t* Q, int64_t m, int64_t n, int V,
                          double rcond, float* T_out, float* A_out, float* b_out) {
     if (V < 1 || V > GANQ_MAX_V) return -1;
     if (rcond < 0) rcond = 1.1920928955078125e-07 * (double)V;
     int fail = 0;
+    const addw_fn addw = pick_addw();
+    const int64_t blocks = (m + UT_R - 1) / UT_R;
 #pragma omp parallel
     {
-        double* G = (double*)malloc(sizeof(double) * (size_t)V * (size_t)(n > 0 ? n : 1)); /* S_i H  [V,n] */
-        double* A = (double*)malloc(sizeof(double) * V * V);
+        double* G = (double*)malloc(sizeof(double) * UT_R * (size_t)V * UT_W); /* strips of S_i H: [UT_R][V][UT_W] */
+        double* Aall = (double*)malloc(sizeof(double) * UT_R * V * V);
         double* E = (double*)malloc(sizeof(double) * V * V);
         double* b = (double*)malloc(sizeof(double) * V);
         double* x = (double*)malloc(sizeof(double) * V);
-        if (!G || !A || !E || !b || !x) {
+        if (!G || !Aall || !E || !b || !x) {
 #pragma omp atomic write
             fail = 1;
         } else {
 #pragma omp for schedule(dynamic, 1)
-            for (int64_t i = 0; i < m; ++i) {
-                const uint8_t* q = Q + i * n;
-                memset(G, 0, sizeof(double) * (size_t)V * (size_t)n);
-                for (int64_t u = 0; u < n; ++u) {
-                    double* g = G + (size_t)q[u] * n;
-                    const float* h = H + u * n;
-                    for (int64_t v = 0; v < n; ++v) g[v] += (double)h[v];
-                }
-                for (int a = 0; a < V * V; ++a) A[a] = 0.0;
-                for (int a = 0; a < V; ++a) {
-                    const double* g = G + (size_t)a * n;
-                    double* arow = A + a * V;
-                    for (int64_t v = 0; v < n; ++v) arow[q[v]] += g[v];
-                }
-                for (int a = 0; a < V; ++a) b[a] = 0.0;
-                for (int64_t u = 0; u < n; ++u) b[q[u]] += (double)WH[i * n + u];
-                for (int a = 0; a < V * V; ++a) A[a] = (double)(float)A[a];
-                for (int a = 0; a < V; ++a) b[a] = (double)(float)b[a];
-                /* symmetrise (H is symmetric up to fp32 noise; the eigen-solve wants exact symmetry) */
-                for (int a = 0; a < V; ++a)
-                    for (int c = a + 1; c < V; ++c) {
-                        double s = 0.5 * (A[a * V + c] + A[c * V + a]);
-                        A[a * V + c] = s;
-                        A[c * V + a] = s;
+            for (int64_t blk = 0; blk < blocks; ++blk) {
+                const int64_t i0 = blk * UT_R;
+                const int R = (int)((m - i0) < UT_R ? (m - i0) : UT_R);
+                for (int a = 0; a < R * V * V; ++a) Aall[a] = 0.0;
+                for (int64_t v0 = 0; v0 < n; v0 += UT_W) {
+                    const int64_t w = (n - v0) < UT_W ? (n - v0) : UT_W;
+                    memset(G, 0, sizeof(double) * (size_t)R * (size_t)V * UT_W);
+                    for (int64_t u = 0; u < n; ++u) {
+                        const float* h = H + u * n + v0;
+                        for (int r = 0; r < R; ++r) {
+                            addw(G + ((size_t)r * V + Q[(i0 + r) * n + u]) * UT_W, h, w);
+                        }
                     }
-                if (A_out)
-                    for (int a = 0; a < V * V; ++a) A_out[i * V * V + a] = (float)A[a];
-                if (b_out)
-                    for (int a = 0; a < V; ++a) b_out[i * V + a] = (float)b[a];
-                minnorm_solve(A, b, V, rcond, x, E);
-                for (int a = 0; a < V; ++a) T_out[i * V + a] = (float)x[a];
+                    for (int r = 0; r < R; ++r) {
+                        const uint8_t* q = Q + (i0 + r) * n + v0;
+                        for (int a = 0; a < V; ++a) {
+                            const double* g = G + ((size_t)r * V + a) * UT_W;
+                            double* arow = Aall + ((size_t)r * V + a) * V;
+                            for (int64_t v = 0; v < w; ++v) arow[q[v]] += g[v];
+                        }
+                    }
+                }
+                for (int r = 0; r < R; ++r) {
+                    const int64_t i = i0 + r;
+                    const uint8_t* q = Q + i * n;
+                    double* A = Aall + (size_t)r * V * V;
+                    for (int a = 0; a < V; ++a) b[a] = 0.0;
+                    for (int64_t u = 0; u < n; ++u) b[q[u]] += (double)WH[i * n + u];
+                    for (int a = 0; a < V * V; ++a) A[a] = (double)(float)A[a];
+                    for (int a = 0; a < V; ++a) b[a] = (double)(float)b[a];
+                    /* symmetrise (H is symmetric up to fp32 noise; the eigen-solve wants exact symmetry) */
+                    for (int a = 0; a < V; ++a)
+                        for (int c = a + 1; c < V; ++c) {
+                            double sy = 0.5 * (A[a * V + c] + A[c * V + a]);
+                            A[a * V + c] = sy;
+                            A[c * V + a] = sy;
+                        }
+                    if (A_out)
+                        for (int a = 0; a < V * V; ++a) A_out[i * V * V + a] = (float)A[a];
+                    if (b_out)
+                        for (int a = 0; a < V; ++a) b_out[i * V + a] = (float)b[a];
+                    minnorm_solve(A, b, V, rcond, x, E);
+                    for (int a = 0; a < V; ++a) T_out[i * V + a] = (float)x[a];
+                }
             }
         }
         free(G);
-        free(A);
+        free(Aall);
         free(E);
         free(b);
         free(x);
@@ -274,19 +360,28 @@ int ganq_oracle_minnorm_solve(const float* A_in, const float* b_in, int64_t m, i
 /* ------------------------------------------------------------------------------------------
  * Dense fp32 product C[m,n] = A[m,k] @ B[k,n] with fp64 accumulation (W@H, ganq.py:590).
  * ------------------------------------------------------------------------------------------ */
+#define MM_R 8
+#define MM_W 448
 int ganq_oracle_matmul(const float* A, const float* B, int64_t m, int64_t k, int64_t n, float* C) {
+    const axpy_fn axpy = pick_axpy();
+    const int64_t blocks = (m + MM_R - 1) / MM_R;
 #pragma omp parallel
     {
-        double* acc = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-#pragma omp for schedule(dynamic, 4)
-        for (int64_t i = 0; i < m; ++i) {
-            for (int64_t v = 0; v < n; ++v) acc[v] = 0.0;
-            for (int64_t u = 0; u < k; ++u) {
-                double a = (double)A[i * k + u];
-                const float* brow = B + u * n;
-                for (int64_t v = 0; v < n; ++v) acc[v] += a * (double)brow[v];
+        double* acc = (double*)malloc(sizeof(double) * MM_R * (size_t)(n > 0 ? n : 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t blk = 0; blk < blocks; ++blk) {  /* MM_R rows share every row of B; each element: one sum over ascending u */
+            const int64_t i0 = blk * MM_R;
+            const int R = (int)((m - i0) < MM_R ? (m - i0) : MM_R);
+            for (int64_t v = 0; v < (int64_t)R * n; ++v) acc[v] = 0.0;
+            for (int64_t v0 = 0; v0 < n; v0 += MM_W) {  /* column strips: the R partial rows of a strip stay in L1 */
+                const int64_t w = (n - v0) < MM_W ? (n - v0) : MM_W;
+                for (int64_t u = 0; u < k; ++u) {
+                    const float* brow = B + u * n + v0;
+                    for (int r = 0; r < R; ++r) axpy(acc + (size_t)r * n + v0, brow, (double)A[(i0 + r) * k + u], w);
+                }
             }
-            for (int64_t v = 0; v < n; ++v) C[i * n + v] = (float)acc[v];
+            for (int r = 0; r < R; ++r)
+                for (int64_t v = 0; v < n; ++v) C[(i0 + r) * n + v] = (float)acc[(size_t)r * n + v];
         }
         free(acc);
     }
@@ -303,22 +398,33 @@ int ganq_oracle_quad_loss(const float* W, const float* H, const float* T, const 
     /* per-row terms first, then one sum in row order: the total does not depend on the OpenMP schedule (two
      * iterations with the same indices must give the same distance bit for bit, best-of-K compares them) */
     double* rows = (double*)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    const axpy_fn axpy = pick_axpy();
+    const int64_t blocks = (m + MM_R - 1) / MM_R;
 #pragma omp parallel
     {
-        float* e = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
-        double* acc = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-#pragma omp for schedule(dynamic, 4)
-        for (int64_t i = 0; i < m; ++i) {
-            for (int64_t u = 0; u < n; ++u) e[u] = W[i * n + u] - T[i * V + Q[i * n + u]];
-            for (int64_t v = 0; v < n; ++v) acc[v] = 0.0;
-            for (int64_t u = 0; u < n; ++u) {
-                double eu = (double)e[u];
-                const float* h = H + u * n;
-                for (int64_t v = 0; v < n; ++v) acc[v] += eu * (double)h[v];
+        float* e = (float*)malloc(sizeof(float) * MM_R * (size_t)(n > 0 ? n : 1));
+        double* acc = (double*)malloc(sizeof(double) * MM_R * (size_t)(n > 0 ? n : 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t blk = 0; blk < blocks; ++blk) {  /* MM_R rows share every row of H; each element: one sum over ascending u */
+            const int64_t i0 = blk * MM_R;
+            const int R = (int)((m - i0) < MM_R ? (m - i0) : MM_R);
+            for (int r = 0; r < R; ++r) {
+                const int64_t i = i0 + r;
+                for (int64_t u = 0; u < n; ++u) e[(size_t)r * n + u] = W[i * n + u] - T[i * V + Q[i * n + u]];
             }
-            double r = 0.0;
-            for (int64_t v = 0; v < n; ++v) r += acc[v] * (double)e[v];
-            rows[i] = r;
+            for (int64_t v = 0; v < (int64_t)R * n; ++v) acc[v] = 0.0;
+            for (int64_t v0 = 0; v0 < n; v0 += MM_W) {
+                const int64_t w = (n - v0) < MM_W ? (n - v0) : MM_W;
+                for (int64_t u = 0; u < n; ++u) {
+                    const float* h = H + u * n + v0;
+                    for (int r = 0; r < R; ++r) axpy(acc + (size_t)r * n + v0, h, (double)e[(size_t)r * n + u], w);
+                }
+            }
+            for (int r = 0; r < R; ++r) {
+                double rs = 0.0;
+                for (int64_t v = 0; v < n; ++v) rs += acc[(size_t)r * n + v] * (double)e[(size_t)r * n + v];
+                rows[i0 + r] = rs;
+            }
         }
         free(e);
         free(acc);
@@ -662,27 +768,79 @@ int ganq_oracle_lut_linear(const uint16_t* x, const uint8_t* Q, const uint16_t* 
  * so the result depends on nothing but A (threads split the rows of a column).  A [n,n] fp32 symmetric (lower
  * triangle read), out [n,n] fp32 lower-triangular (upper part zero).  Returns j+1 when pivot j is not positive.
  * ------------------------------------------------------------------------------------------ */
+/* Blocked form (round 4; n = 14336 inputs): the columns are taken DC_B at a time so that a row's DC_B sums share every load
+ * of the row -- the chains of different entries are independent, the chain of ONE entry is still the single ascending
+ * sequence of separately rounded products and subtractions above, so the bits are those of the plain Crout loop (the
+ * fixtures' sha256 of L, made with the plain loop in round 3, are the check).  No FMA: -ffp-contract=off, and the AVX2
+ * clone carries no FMA flag. */
+#define DC_B 16
+
+/* the sums over k < J0 of one row: t[c] = a[c] - sum_k Li[k] * P[k][c], k ascending (P = the block's rows, transposed) */
+__attribute__((target_clones("avx2", "default")))
+static void dc_row_partial(const double* Li, const double* P, int64_t J0, double* t) {
+    double acc[DC_B];
+    for (int c = 0; c < DC_B; ++c) acc[c] = t[c];
+    for (int64_t k = 0; k < J0; ++k) {
+        const double lik = Li[k];
+        const double* Pk = P + k * DC_B;
+#pragma omp simd
+        for (int c = 0; c < DC_B; ++c) acc[c] -= lik * Pk[c];
+    }
+    for (int c = 0; c < DC_B; ++c) t[c] = acc[c];
+}
+
 int ganq_oracle_det_cholesky(const float* A, int64_t n, float* out) {
     double* Ld = (double*)calloc((size_t)n * (size_t)n, sizeof(double));
-    if (!Ld) return -1;
+    double* P = (double*)malloc((size_t)n * DC_B * sizeof(double));
+    if (!Ld || !P) { free(Ld); free(P); return -1; }
     int bad = 0;
-    for (int64_t j = 0; j < n && !bad; ++j) {
-        const double* Lj = Ld + j * n;
-        double s = (double)A[j * n + j];
-        for (int64_t k = 0; k < j; ++k) s -= Lj[k] * Lj[k];
-        if (!(s > 0.0)) { bad = (int)(j + 1); break; }
-        const double d = sqrt(s);
-        Ld[j * n + j] = d;
+    for (int64_t J0 = 0; J0 < n && !bad; J0 += DC_B) {
+        const int bw = (int)((n - J0) < DC_B ? (n - J0) : DC_B);
+        /* the block's own rows, transposed: P[k][c] = L[J0+c][k], k < J0 (columns beyond bw: zeros) */
 #pragma omp parallel for schedule(static)
-        for (int64_t i = j + 1; i < n; ++i) {
-            const double* Li = Ld + i * n;
-            double t = (double)A[i * n + j];
-            for (int64_t k = 0; k < j; ++k) t -= Li[k] * Lj[k];
-            Ld[i * n + j] = t / d;
+        for (int64_t k = 0; k < J0; ++k)
+            for (int c = 0; c < DC_B; ++c) P[k * DC_B + c] = c < bw ? Ld[(J0 + c) * n + k] : 0.0;
+        /* diagonal block: rows J0 .. J0+bw-1, one after the other */
+        double d[DC_B];
+        for (int r = 0; r < bw && !bad; ++r) {
+            const int64_t j = J0 + r;
+            double t[DC_B];
+            for (int c = 0; c < DC_B; ++c) t[c] = (c <= r) ? (double)A[j * n + J0 + c] : 0.0;
+            dc_row_partial(Ld + j * n, P, J0, t);
+            double* Lj = Ld + j * n;
+            for (int c = 0; c < r; ++c) {          /* L[j][J0+c], c < r: continue the sum over k = J0 .. J0+c-1 */
+                double v = t[c];
+                const double* Lc = Ld + (J0 + c) * n;
+                for (int64_t k = J0; k < J0 + c; ++k) v -= Lj[k] * Lc[k];
+                Lj[J0 + c] = v / d[c];
+            }
+            double s = t[r];
+            for (int64_t k = J0; k < j; ++k) s -= Lj[k] * Lj[k];
+            if (!(s > 0.0)) { bad = (int)(j + 1); break; }
+            d[r] = sqrt(s);
+            Lj[j] = d[r];
+        }
+        if (bad) break;
+        /* the rows below the block */
+#pragma omp parallel for schedule(dynamic, 16)
+        for (int64_t i = J0 + bw; i < n; ++i) {
+            double t[DC_B];
+            for (int c = 0; c < DC_B; ++c) t[c] = (c < bw) ? (double)A[i * n + J0 + c] : 0.0;
+            double* Li = Ld + i * n;
+            dc_row_partial(Li, P, J0, t);
+            for (int c = 0; c < bw; ++c) {
+                double v = t[c];
+                const double* Lc = Ld + (J0 + c) * n;
+                for (int64_t k = J0; k < J0 + c; ++k) v -= Li[k] * Lc[k];
+                Li[J0 + c] = v / d[c];
+            }
         }
     }
-    if (!bad)
+    if (!bad) {
+#pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < n * n; ++i) out[i] = (float)Ld[i];
+    }
     free(Ld);
+    free(P);
     return bad;
 }

@@ -28,38 +28,64 @@ def sha(a) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def make(m: int, n: int, bits: int, seed: int, tokens: int):
-    """-> dict(W [m,n] f32 (permuted columns), H = Xxt_damped [n,n] f32, L [n,n] f32 lower, hinv_diag [n] f32,
-    T0 [m,V] f32, perm [n] int64, damp float)"""
+_base_cache = {}
+
+
+def _base(m: int, n: int, seed: int, tokens: int):
+    """everything but T0 (which depends on `bits`); the last result is kept: cases that differ only in `bits` share it"""
+    key = (m, n, seed, tokens)
+    if key in _base_cache:
+        return _base_cache[key]
+    _base_cache.clear()
     rng = np.random.default_rng(seed)
     Z = rng.integers(-7, 8, size=(tokens, n)).astype(np.float64)
     X = Z + np.roll(Z, 1, axis=1)                       # neighbouring features correlate (0.5)
+    del Z
     e = rng.integers(-2, 2, size=n)
-    G = X.T @ X                                          # integers < 2^21: exact in fp64 whatever the BLAS does
+    G = X.T @ X                                          # integers < 2^22: exact in fp64 whatever the BLAS does
+    del X
     nseq = max(1, tokens // 2048) * 4                    # the 2/N of gptq.py:122-131 as a power of two
-    H = G * np.exp2(e)[:, None] * np.exp2(e)[None, :] * (2.0 / nseq) / 1024.0
-    assert np.array_equal(H, H.astype(np.float32).astype(np.float64))
+    G *= np.exp2(e)[:, None]
+    G *= np.exp2(e)[None, :] * ((2.0 / nseq) / 1024.0)   # powers of two: every step exact
+    H = G
+    H32 = H.astype(np.float32)
+    assert np.array_equal(H, H32)
     # bell-shaped weights from integers only (sum of four uniform integers, std 0.018), rounded to fp16 like a module's
     Wi = rng.integers(-1023, 1024, size=(4, m, n)).sum(axis=0)
     W = (Wi.astype(np.float32) * np.float32(2.0 ** -16)).astype(np.float16).astype(np.float32)
     d = np.diag(H).copy()
     perm = np.argsort(d, kind="stable")                  # act_sort = "asc" (gptq.py:281-286)
     W = np.ascontiguousarray(W[:, perm])
-    H = np.ascontiguousarray(H[perm][:, perm])
-    offset = np.clip(np.abs(H).sum(axis=1) - 2.0 * np.diag(H), 1e-8, None).astype(np.float32)  # gptq.py:289-291
-    H32 = H.astype(np.float32)
+    H32 = np.ascontiguousarray(H32[perm][:, perm])
+    del H, G
+    idx = np.arange(n)
+    rowabs = np.array([np.abs(H32[i].astype(np.float64)).sum() for i in range(n)])  # exact: multiples of one power of two
+    dg = H32[idx, idx].astype(np.float64)
+    offset = np.clip(rowabs - 2.0 * dg, 1e-8, None).astype(np.float32)  # gptq.py:289-291
+    damp = np.float32(0.01 * dg.mean())                  # gptq.py:296-298
     A1 = H32.copy()
-    A1[np.arange(n), np.arange(n)] += offset
+    A1[idx, idx] += offset
     L = c_oracle.det_cholesky(A1)
-    damp = np.float32(0.01 * np.diag(H).mean())          # gptq.py:296-298
-    Hd = H32.copy()
-    Hd[np.arange(n), np.arange(n)] += damp
+    del A1
+    Hd = H32
+    Hd[idx, idx] += damp
     Lr = c_oracle.det_cholesky(np.ascontiguousarray(Hd[::-1, ::-1]))
     hinv_diag = (np.float32(1.0) / np.diag(Lr)[::-1]).astype(np.float32)
+    del Lr
+    out = dict(W=W, H=Hd, L=L, hinv_diag=hinv_diag, perm=perm.astype(np.int64), damp=float(damp))
+    _base_cache[key] = out
+    return out
+
+
+def make(m: int, n: int, bits: int, seed: int, tokens: int):
+    """-> dict(W [m,n] f32 (permuted columns), H = Xxt_damped [n,n] f32, L [n,n] f32 lower, hinv_diag [n] f32,
+    T0 [m,V] f32, perm [n] int64, damp float)"""
+    out = dict(_base(m, n, seed, tokens))
+    hinv_diag = out["hinv_diag"]
     h2 = hinv_diag * hinv_diag                            # ganq.py:427-429: diag(Hinv)^-4 in fp32, by exact elementwise
     weights = np.float32(1.0) / (h2 * h2)                 # operations (a library pow() may round differently per CPU)
-    T0 = c_oracle.kmeans_init(W, weights.astype(np.float64), 2 ** bits)
-    return dict(W=W, H=Hd, L=L, hinv_diag=hinv_diag, T0=T0, perm=perm.astype(np.int64), damp=float(damp))
+    out["T0"] = c_oracle.kmeans_init(out["W"], weights.astype(np.float64), 2 ** bits)
+    return out
 
 
 def hashes(inp) -> dict:

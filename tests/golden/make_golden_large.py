@@ -44,6 +44,13 @@ CASES = [
     dict(name="h3072x768_b4_k10", m=3072, n=768, bits=4, K=10, seed=206, tokens=2048, hash_only=True),
     dict(name="h768x3072_b4_k10", m=768, n=3072, bits=4, K=10, seed=207, tokens=4096, hash_only=True),
     dict(name="h768x768_b4_k10", m=768, n=768, bits=4, K=10, seed=208, tokens=2048, hash_only=True),
+    # round 4: the long chains of the Llama shapes (down_proj: n = 8192 in Llama-3.2-1B, n = 14336 in Llama-3-8B) on a few rows --
+    # rows are independent in every stage (ganq.py:525-634), so 32 / 64 rows cost the reference seconds -- and a whole layer
+    # at V = 8 (BASELINE.json configs[4]); the residual gemv of ganq.py:564-565 sums up to 14335 products here
+    dict(name="l64x8192_b4_k3", m=64, n=8192, bits=4, K=3, seed=211, tokens=8192, hash_only=False),
+    dict(name="l32x14336_b4_k2", m=32, n=14336, bits=4, K=2, seed=212, tokens=16384, hash_only=False),
+    dict(name="l32x14336_b3_k2", m=32, n=14336, bits=3, K=2, seed=212, tokens=16384, hash_only=False),
+    dict(name="h1024x4096_b3_k2", m=1024, n=4096, bits=3, K=2, seed=213, tokens=8192, hash_only=True),
     # torch.argmin's NaN semantics in the S-solve (ganq.py:547): two codebook entries are NaN; only the S-solve of the one
     # iteration is captured (what lstsq / the loss make of NaN inputs is not part of the contract: gptq.py:328-330 raises)
     dict(name="nan48x256_b4_k1", m=48, n=256, bits=4, K=1, seed=205, tokens=1024, hash_only=False, nan_entries=[(3, 6), (10, 0), (10, 9)]),

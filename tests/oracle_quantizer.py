@@ -153,3 +153,60 @@ class OracleProcessor(GPTQProcessor):
         tmp = OracleGANQ(module, copy.deepcopy(self.qcfg))
         tmp.quantizer.configure(perchannel=True)
         self.tasks[module.name] = tmp
+
+
+def reference_prologue_ops(self, W, H):
+    """TEST INFRASTRUCTURE (moved out of the product in round 4): the reference's own prologue op sequence (gptq.py:267-316) on
+    torch.linalg, with the signature of `ganq_amd.quantization.GPTQ._prologue_hip` -- the checker the HIP prologue is compared
+    with.  `self` is a product GPTQ/GANQ object; Hinv is returned as the full upper factor, as the reference does."""
+    dead = torch.diag(H) == 0
+    H[dead, dead] = 1
+    if self.qcfg.dead == "zero":
+        W[:, dead] = 0
+    elif self.qcfg.dead == "mean":
+        W[:, dead] = torch.mean(W[:, ~dead], dim=1, keepdim=True)
+    else:
+        assert False, f"Unknown dead mode: {self.qcfg.dead}"
+
+    perm = None
+    invperm = None
+    if self.qcfg.act_sort != "none":
+        assert self.qcfg.act_sort in ["asc", "desc"]
+        perm = torch.argsort(torch.diag(H), descending=self.qcfg.act_sort == "desc")
+        W = W[:, perm].contiguous()
+        H = H[perm][:, perm].contiguous()
+        invperm = torch.argsort(perm)
+
+    self.Xxt = H.clone()  # undamped
+    if self.qcfg.l_damp_style == "ganq":
+        offset = (torch.sum(torch.abs(H), dim=1) - 2 * torch.diag(H)).clamp(min=1e-8)
+        self.L = torch.linalg.cholesky(H + torch.diag(offset))
+
+    damp_percent = self.qcfg.damp_percent
+    Hinv = None
+    while 1 > damp_percent > 0:
+        try:
+            damp = damp_percent * torch.mean(torch.diag(H))
+            diag = torch.arange(self.columns, device=self.device)
+            H[diag, diag] += damp
+            self.Xxt_damped = H.clone()
+            L = torch.linalg.cholesky(H)
+            if self.qcfg.l_damp_style == "gptq":
+                self.L = L.clone()
+            Hinv = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
+            break
+        except torch._C._LinAlgError as e:
+            if self.qcfg.damp_auto_increment != 0:
+                damp_percent += self.qcfg.damp_auto_increment
+            else:
+                raise e
+    return W, dead, perm, invperm, Hinv, damp_percent
+
+
+def use_reference_prologue(q):
+    """make the product quantizer object `q` run the reference's prologue op sequence (above) instead of the HIP prologue --
+    A/B runs in the tests only; the product has no such switch"""
+    import types
+
+    q._prologue_hip = types.MethodType(reference_prologue_ops, q)
+    return q

@@ -19,6 +19,22 @@ LARGE = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.pa
 TOL_T, TOL_LOSS = 1e-5, 1e-6
 _cache = {}
 
+# Free-running budgets (round 4: per case, about twice what was measured, instead of one formula 3-20 x looser).
+# Stage-wise -- the reference's codebook in, its indices out -- every case is bit-exact, oracle and HIP alike, with no budget.
+# Free-running, iteration k solves against the path's OWN codebook, which agrees with the reference's to ~1e-7 (the reference
+# holds A, b in fp32 and solves by SVD; the oracle rounds A, b to fp32 and solves in fp64; the HIP path keeps A exact and solves
+# in fp64): a near-tie of the next S-solve -- about one index in 10^6 .. 10^7 -- may then fall the other way, and the row is on
+# a trajectory of its own from there.  What is bounded is the number of rows LEAVING the reference's trajectory: (most in any
+# one iteration, total over the K iterations).  Measured (MI355X, round 4; DESIGN.md section 2 lists the vectors):
+#   h4096x4096_b4_k2 [0, 19]; h3072x768_b4_k10 [0,4,1,0,3,1,0,0,1,1]; h768x3072_b4_k10 [0,3,8,1,1,2,0,2,2,1];
+#   h768x768_b4_k10 [0,1,2,0,1,1,0,0,0,0]; h1024x4096_b3_k2, l64x8192_b4_k3, l32x14336_b4_k2, l32x14336_b3_k2: see HIP_LEAVING
+HIP_LEAVING = {
+    "h4096x4096_b4_k2": (40, 40), "h3072x768_b4_k10": (8, 22), "h768x3072_b4_k10": (16, 40), "h768x768_b4_k10": (4, 10),
+    "h1024x4096_b3_k2": (4, 4), "l64x8192_b4_k3": (1, 2), "l32x14336_b4_k2": (1, 2), "l32x14336_b3_k2": (1, 2),
+}
+# the CPU oracle, free-running: rows leaving (the small traced cases: none); measured l32x14336_b4_k2 [0, 1]
+ORACLE_LEAVING = {"l64x8192_b4_k3": (1, 1), "l32x14336_b4_k2": (1, 2), "l32x14336_b3_k2": (1, 1)}
+
 
 def case(name):
     if name not in _cache:
@@ -36,7 +52,8 @@ def case(name):
 
 def test_large_cases_present():
     assert {"l128x2048_b4_k3", "l128x2048_b3_k3", "l128x2048_b4_k10", "l256x512_b2_k3", "h4096x4096_b4_k2",
-            "h3072x768_b4_k10", "h768x3072_b4_k10", "h768x768_b4_k10", "nan48x256_b4_k1"} <= set(LARGE)
+            "h3072x768_b4_k10", "h768x3072_b4_k10", "h768x768_b4_k10", "nan48x256_b4_k1",
+            "l64x8192_b4_k3", "l32x14336_b4_k2", "l32x14336_b3_k2", "h1024x4096_b3_k2"} <= set(LARGE)
 
 
 # ------------------------------------------------------------------------------------------ CPU oracle
@@ -57,10 +74,19 @@ def test_oracle_vs_reference_large(name):
         assert abs(d - fx["dists"][k]) <= TOL_LOSS * abs(fx["dists"][k])
     tr = c_oracle.run_layer_trace(inp["W"], inp["H"], inp["L"], inp["T0"], K)  # free-running
     flips = [int((tr["Q_all"][k] != Qs[k]).sum()) for k in range(K)]
-    print(f"{name}: free-running index flips per iteration vs the reference: {flips}")
-    assert sum(flips) == 0
-    assert all(rel_fro(tr["T_all"][k], fx["T"][k + 1]) < TOL_T for k in range(K))
-    assert np.allclose(tr["dists"], fx["dists"], rtol=TOL_LOSS)
+    differ = np.stack([(tr["Q_all"][k] != Qs[k]).any(axis=1) for k in range(K)])
+    left = np.zeros(differ.shape[1], dtype=bool)
+    leaving = []
+    for k in range(K):
+        leaving.append(int((differ[k] & ~left).sum()))
+        left |= differ[k]
+    print(f"{name}: oracle free-running vs the reference: index flips per iteration {flips}, rows leaving its trajectory {leaving}")
+    per_it, total = ORACLE_LEAVING.get(name, (0, 0))
+    assert max(leaving) <= per_it and sum(leaving) <= total, f"{name}: rows leaving the reference's trajectory {leaving}"
+    assert not differ[0].any()  # the first solve starts from the reference's own T0
+    clean = ~left
+    assert all(rel_fro(tr["T_all"][k][clean], fx["T"][k + 1][clean]) < TOL_T for k in range(K))
+    assert np.allclose(tr["dists"], fx["dists"], rtol=TOL_LOSS if not left.any() else 1e-4)
     best = int(np.argmin(fx["dists"]))
     Wq, Lo = c_oracle.dequant_losses(inp["W"], fx["T"][best + 1], Qs[K - 1], inp["hinv_diag"])
     assert exact_inputs.sha(Wq) == str(fx["sha_Wq"])
@@ -163,12 +189,13 @@ def test_hip_vs_reference_large(hip, name):
     # (the reference holds A, b in fp32 and solves by SVD; here A is exact and the solve fp64): a near-tie -- about one index
     # in 10^6..10^7 -- may then fall the other way.  From there the row is on a trajectory of its own (the flip moves the
     # residual of every later column, the next codebook, ...), so what is bounded is the number of rows LEAVING the
-    # reference's trajectory per iteration: none on the small traced cases; on the whole layers (4096 x 4096, the opt-125m
-    # module shapes over K = 10) at most 4e-6 per index solved (and at least 3).  Every row off the reference, in every
+    # reference's trajectory per iteration: none on the small traced cases; elsewhere the case's budget (HIP_LEAVING: twice
+    # what was measured).  Every row off the reference, in every
     # iteration, must be exactly what the CPU oracle computes from the path's own previous codebook -- so a difference is the
     # codebook's rounding, never the solve -- and the rows still on the trajectory keep the reference's codebooks.
-    budget = 0 if not hash_only else max(3, int(4e-6 * m * int(fx["n"])))
-    assert max(leaving) <= budget, f"{name}: rows leaving the reference's trajectory {leaving} exceed {budget} per iteration"
+    per_it, total = HIP_LEAVING.get(name, (0, 0))
+    assert max(leaving) <= per_it and sum(leaving) <= total, \
+        f"{name}: rows leaving the reference's trajectory {leaving} exceed the case's budget ({per_it} per iteration, {total} in all)"
     if left.any():
         from oracle import c_oracle
 

@@ -22,10 +22,13 @@ def make_quantizer(g, lin=None, prologue="hip"):
             lin.bias.copy_(torch.from_numpy(g["bias"]))
     qcfg = QuantizeConfig(bits=int(g["bits"]), quant_method="ganq", format="ganq_lut", act_sort=str(g["act_sort"]),
                           l_damp_style=str(g["l_damp_style"]), dead=str(g["dead"]), desc_act=bool(g["desc_act"]),
-                          ganq_iterations=int(g["K"]), group_size=int(g["group_size"]), damp_percent=0.01,
-                          ganq_prologue=prologue)
+                          ganq_iterations=int(g["K"]), group_size=int(g["group_size"]), damp_percent=0.01)
     q = GANQ(NamedModule(lin, "fc1", "model.layers.0.fc1", 0), qcfg)
     q.quantizer.configure(perchannel=True)
+    if prologue == "torch":  # the reference's op sequence on torch.linalg: test infrastructure (tests/oracle_quantizer.py)
+        from oracle_quantizer import use_reference_prologue
+
+        use_reference_prologue(q)
     return q, lin
 
 
@@ -110,9 +113,12 @@ def test_quantize_with_reference_prologue_injected_is_exact(name):
 
     qcfg = QuantizeConfig(bits=int(g["bits"]), quant_method="ganq", format="ganq_lut", act_sort=str(g["act_sort"]),
                           l_damp_style=str(g["l_damp_style"]), dead=str(g["dead"]), desc_act=bool(g["desc_act"]),
-                          ganq_iterations=int(g["K"]), group_size=int(g["group_size"]), damp_percent=0.01, ganq_prologue="torch")
+                          ganq_iterations=int(g["K"]), group_size=int(g["group_size"]), damp_percent=0.01)
     q = InjectedGANQ(NamedModule(lin, "fc1", "model.layers.0.fc1", 0), qcfg)
     q.quantizer.configure(perchannel=True)
+    from oracle_quantizer import use_reference_prologue
+
+    use_reference_prologue(q)
     for xb in g["X"]:
         q.add_batch(torch.from_numpy(xb).cuda(), None)
     wq, scale, zero, g_idx, duration, avg_loss, damp = q.quantize()
@@ -158,10 +164,13 @@ def test_damp_retry_on_indefinite_hessian(prologue):
     X = torch.randn(1, 32, n, device="cuda").half()  # 32 tokens for 256 features: rank-deficient H
 
     def run(**kw):
-        qcfg = QuantizeConfig(bits=4, act_sort="none", desc_act=False, l_damp_style="ganq", dead="zero", ganq_iterations=1,
-                              ganq_prologue=prologue, **kw)
+        qcfg = QuantizeConfig(bits=4, act_sort="none", desc_act=False, l_damp_style="ganq", dead="zero", ganq_iterations=1, **kw)
         q = GANQ(NamedModule(lin, "fc", "layers.0.fc", 0), qcfg)
         q.quantizer.configure(perchannel=True)
+        if prologue == "torch":
+            from oracle_quantizer import use_reference_prologue
+
+            use_reference_prologue(q)
         q.add_batch(X, None)
         q.hessian.sub_(0.05 * torch.diag(q.hessian).mean() * torch.eye(n, device="cuda"))  # push the null space below zero
         return q.quantize()

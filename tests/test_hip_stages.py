@@ -182,19 +182,33 @@ def test_solve_s_helper_workgroups_bit_identical(hip, oracle, m, n, V, seed, lib
     assert np.array_equal(Q0.cpu().numpy()[rows], oracle.solve_s(W[rows], L, T0[rows]))
 
 
-def test_solve_s_helper_workgroups_on_concurrent_streams(hip):
-    """Two helped launches at once (the looper quantizes the followers of a group on side streams): each asks for 128 tiles + 128
-    helpers, together twice the chip.  Whatever subset of the workgroups is resident, a tile either has its helper or finishes
-    without it -- the indices must be those of the launches run one after the other, and nothing may hang."""
+def test_solve_s_helper_workgroups_on_concurrent_streams(hip, lib_options):
+    """Three helped launches at once (round 3's looper quantized the followers of a group on side streams with helpers; a
+    second process on the GPU does the same to any launch): each asks for 128 tiles + 128 helpers, together three times the
+    chip.  Whatever subset of the workgroups is resident, a tile either has its helper or finishes without it -- the indices
+    must be those of the launches run one after the other -- and a helper that is not resident may cost a tile ONE wait of
+    DUO_TIMEOUT (0.5 ms since round 4; 0.2 s before), so the three launches side by side must not take much longer than one
+    after the other; the same bound holds for helpers that never answer (GANQ_SOLVE_DUO=2)."""
+    import time
+
     outs, data = [], []
     for seed in (41, 42, 43):
         W, H, L, T0 = synth(2048, 1024, 16, seed, corr=0.1)
         data.append((dev(W), dev(L), dev(T0)))
     ref = [hip.solve_s(*d) for d in data]
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        for d in data:
+            hip.solve_s(*d)
+    torch.cuda.synchronize()
+    t_seq = (time.perf_counter() - t0) / 3
     streams = [torch.cuda.Stream() for _ in data]
+    t_conc = []
     for _ in range(3):
         outs = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         for st, d in zip(streams, data):
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
@@ -202,8 +216,21 @@ def test_solve_s_helper_workgroups_on_concurrent_streams(hip):
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
+        t_conc.append(time.perf_counter() - t0)
         for o, r in zip(outs, ref):
             assert torch.equal(o, r)
+    lib_options(GANQ_SOLVE_DUO=2)  # helpers that never answer: every chain wave times out once, then works alone
+    hip.solve_s(*data[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Qm = hip.solve_s(*data[0])
+    torch.cuda.synchronize()
+    t_muted = time.perf_counter() - t0
+    assert torch.equal(Qm, ref[0])
+    print(f"solve_s 2048 x 1024, three launches: one after the other {t_seq * 1e3:.2f} ms, side by side {min(t_conc) * 1e3:.2f} .. "
+          f"{max(t_conc) * 1e3:.2f} ms; one launch with muted helpers {t_muted * 1e3:.2f} ms")
+    assert max(t_conc) < 2.0 * t_seq + 5e-3, "helped launches side by side wait for each other (time-outs?)"
+    assert t_muted < t_seq / 3 * 2.0 + 5e-3, "a tile whose helper never answers must lose about one DUO_TIMEOUT, not more"
 
 
 def test_solve_s_strided_L_and_empty(hip, oracle):

@@ -1,5 +1,5 @@
 """Warm wall time of a full GANQ.quantize() (prologue + k-means + K iterations + epilogue) and of its phases.
-usage: python tools/time_quantize.py [m n] [prologue]"""
+usage: python tools/time_quantize.py [m n]"""
 import os, sys, time
 import torch, torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,13 +8,12 @@ from ganq_amd.looper.named_module import NamedModule
 from ganq_amd import _lib
 
 m, n = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4096, 4096)
-prologue = sys.argv[3] if len(sys.argv) > 3 else "hip"
 dev = "cuda"
 torch.manual_seed(0)
 lin = nn.Linear(n, m, bias=False).half().to(dev)
 lin.weight.data = (0.02 * torch.randn(m, n, device=dev)).half()
 qcfg = QuantizeConfig(bits=4, act_sort="asc", l_damp_style="ganq", dead="mean", damp_percent=0.01, desc_act=True,
-                      group_size=128, ganq_iterations=10, ganq_prologue=prologue)
+                      group_size=128, ganq_iterations=10)
 scale = 0.1 + torch.rand(n, device=dev)
 xs = [(torch.randn(2048, n, device=dev) * scale).half() for _ in range(8)]
 
