@@ -33,7 +33,9 @@ replays, weights hot in the Infinity Cache and cold from HBM), `opt125m` (BASELI
 on the opt-125m architecture -- 72 linears, 128 x 2048 tokens, K = 10, forward passes included -- next to the C oracle's loop on
 the same module shapes) and `ppl` (Wiki2 perplexity through tools/eval_ppl.py when --model-path / --wikitext-path [/ --c4-path]
 or GANQ_MODEL_PATH / GANQ_WIKITEXT_PATH / GANQ_C4_PATH name local files; "unmeasured: ..." otherwise -- the boxes have no
-network).
+network); round 4: `llama32_1b` (whole-model run on the Llama-3.2-1B architecture, BASELINE configs[2]), `stress_3bit`
+(V = 8, 512 calibration sequences: Hessian seconds + loop ms, BASELINE configs[4]) and `ppl_tiny` (a TRAINED tiny model:
+GPTQ-style PPL of this path next to the reference's own GANQ on the same model and calibration batches).
 """
 import argparse
 import json
@@ -311,6 +313,83 @@ def opt125m_report(args, cap_unused=None):
     return rep
 
 
+def llama32_1b_report(args):
+    """BASELINE.json configs[2]: whole-model quantization of the Llama-3.2-1B ARCHITECTURE (random weights -- no checkpoint is
+    reachable), 112 linears, 128 x 2048 synthetic tokens, K = 10, forward passes included, as columns/s"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import quantize_model_bench as qmb
+
+    qmb.run("llama-3.2-1b", nsamples=16, seqlen=512, batch=8, iters=2, layers=1)  # warm-up: workspaces, library handles
+    rep = qmb.run("llama-3.2-1b", nsamples=args.nseq, seqlen=args.seqlen, batch=8, bits=args.bits, iters=args.iters)
+    rep["what"] = "Llama-3.2-1B architecture at its real dimensions, random weights, whole run incl. forward passes, Hessians, k-means"
+    return rep
+
+
+def stress_3bit_report(args, dist, dev):
+    """BASELINE.json configs[4]: 3-bit (V = 8), 512 calibration sequences (p = 1 M tokens) on the 4096 x 4096 layer: the
+    Hessian accumulation of all 512 x 2048 tokens (seconds) and the K = 10 loop (ms), the same definitions as the headline"""
+    import copy
+
+    from ganq_amd import _lib
+
+    a = copy.copy(args)
+    a.bits, a.nseq, a.mode = 3, 512, "layers"
+    cap, setup = build_workload(a, dist, dev)
+    ws = _lib.run_layer_workspace(a.m, a.n, 8, dev)
+    for _ in range(2):
+        out = _lib.run_layer(cap["W"], cap["H"], cap["L"], cap["T0"], a.iters, alias_q=True, workspace=ws)
+    torch.cuda.synchronize()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = _lib.run_layer(cap["W"], cap["H"], cap["L"], cap["T0"], a.iters, alias_q=True, workspace=ws)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tokens = a.nseq * a.seqlen
+    return {"what": f"synthetic {a.m}x{a.n} layer, 3-bit (V=8), K={a.iters}, {a.nseq}x{a.seqlen} fp16 calibration tokens (BASELINE configs[4])",
+            "hessian_s": setup["hessian_s"], "hessian_tokens": tokens,
+            "hessian_TFLOPs_by_2pn2": round(2.0 * tokens * a.n * a.n / setup["hessian_s"] / 1e12, 1),
+            "kmeans_s": setup["kmeans_s"], "full_quantize_warm_s": setup["full_quantize_warm_s"],
+            "loop_ms": round(dt * 1e3, 3), "columns_per_s": round(a.n / dt, 1),
+            "dists": [round(float(x), 6) for x in out[2].cpu().tolist()], "best_k": int(out[3])}
+
+
+def ppl_tiny_report():
+    """The PPL half of the metric on TRAINED weights without a download: the committed tiny OPT model (tests/golden/tiny_lm,
+    trained on text that ships with the interpreter) quantized by this path on the calibration batches the reference's own
+    GANQ was given; GPTQ-style PPL on held-out text next to the fixture's fp / reference-GANQ figures."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_tiny_lm as tiny
+
+    from ganq_amd.models.quantize import gptq_style_ppl, quantize_model
+    from ganq_amd.quantization import QuantizeConfig
+
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "tiny_lm", "fixture.npz"))
+    ev = torch.from_numpy(fx["eval_ids"].astype(np.int64))
+    out = {"what": "4-layer OPT architecture (hidden 256), trained; 4-bit GANQ K=10 with the reference's recipe, 64 x 512 calibration "
+                   "tokens; GPTQ-style PPL (byte-level tokens) on held-out text; reference = the reference's own GANQ object on the CPU "
+                   "(tests/golden/make_golden_tiny_lm.py)",
+           "ppl_fp_reference_run": round(float(fx["ppl_fp"]), 4), "ppl_ganq_reference": round(float(fx["ppl_ref"]), 4)}
+    for tag, dtype, fmt in (("fp32_fake", torch.float32, "fake"), ("fp16_packed", torch.float16, "ganq_lut")):
+        model = tiny.load_model(dtype).cuda()
+        qcfg = QuantizeConfig(bits=4, quant_method="ganq", format=fmt, act_sort="asc", l_damp_style="ganq", dead="mean",
+                              desc_act=True, ganq_iterations=10, group_size=128, damp_percent=0.01)
+        batches = [torch.from_numpy(fx["calib"][i:i + 1].astype(np.int64)).cuda() for i in range(fx["calib"].shape[0])]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        quantize_model(model, batches, qcfg)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ppl = gptq_style_ppl(model, ev, seqlen=int(fx["seq"]))
+        out[f"ppl_ganq_hip_{tag}"] = round(ppl, 4)
+        out[f"delta_vs_reference_{tag}"] = round(ppl - float(fx["ppl_ref"]), 4)
+        out[f"quantize_s_{tag}"] = round(dt, 3)
+    out["within_0.05_of_reference"] = bool(abs(out["delta_vs_reference_fp32_fake"]) <= 0.05)
+    return out
+
+
 def ppl_report(args):
     """Wiki2 PPL of opt-125m fp16 / GANQ 4-bit (README.md:21-27 of the reference) when the files are on this box"""
     model = args.model_path or os.environ.get("GANQ_MODEL_PATH")
@@ -394,6 +473,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lut", action="store_true", help="skip the lut_forward object")
     ap.add_argument("--no-opt125m", action="store_true", help="skip the opt125m object (whole-model run on the opt-125m architecture)")
+    ap.add_argument("--no-llama", action="store_true", help="skip the llama32_1b object (whole-model run on the Llama-3.2-1B architecture)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the stress_3bit object (V = 8, 512 calibration sequences)")
+    ap.add_argument("--no-tiny", action="store_true", help="skip the ppl_tiny object (trained tiny model, PPL vs the reference's GANQ)")
     ap.add_argument("--model-path", default=None, help="local HF model directory: adds measured Wiki2 PPL (fp16 / GANQ) to the line")
     ap.add_argument("--wikitext-path", default=None)
     ap.add_argument("--c4-path", default=None)
@@ -585,6 +667,18 @@ def main():
             cap = ws = None
             torch.cuda.empty_cache()
             result["opt125m"] = opt125m_report(args)
+        if dist.world == 1 and not args.no_llama:
+            log("[bench] llama32_1b (whole-model run on the architecture) ...")
+            torch.cuda.empty_cache()
+            result["llama32_1b"] = llama32_1b_report(args)
+        if dist.world == 1 and not args.no_stress:
+            log("[bench] stress_3bit (V = 8, 512 sequences) ...")
+            torch.cuda.empty_cache()
+            result["stress_3bit"] = stress_3bit_report(args, dist, dev)
+        if dist.world == 1 and not args.no_tiny:
+            log("[bench] ppl_tiny (trained tiny model vs the reference's GANQ) ...")
+            torch.cuda.empty_cache()
+            result["ppl_tiny"] = ppl_tiny_report()
         if dist.world == 1:
             result["ppl"] = ppl_report(args)
         print(json.dumps(result), flush=True)

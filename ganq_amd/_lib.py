@@ -33,6 +33,7 @@ SIGNATURES = {
     "ganq_hip_selftest": (ctypes.c_int, [_c_vp]),
     "ganq_debug_div_check": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _c_vp, _c_vp, _c_vp]),
     "ganq_debug_wh_product": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp]),
+    "ganq_debug_gemm_h16": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp]),
     "ganq_hessian_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
     "ganq_cholesky_workspace_bytes": (_c_sz, [_c_i64]),
@@ -398,6 +399,19 @@ def _act_dtype(t, name):
     if not t.is_cuda:
         raise GanqHipError(f"{name} must live on the GPU; the HIP path has no CPU fallback")
     return _DTYPE_CODE[t.dtype]
+
+
+def debug_gemm_h16(x, w, bias=None, addend=None):
+    """developer / tests: y = x @ w.T (+ bias) (+ addend) by csrc/gemm_h16.hip; x [M,K], w [N,K] fp16 / bf16"""
+    code = _act_dtype(x, "x")
+    if w.dtype != x.dtype or not w.is_cuda:
+        raise GanqHipError("w must have x's dtype and live on the GPU")
+    x, w = x.contiguous(), w.contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _call("ganq_debug_gemm_h16", (x, w, y), x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(addend), code, M, N, K, y.data_ptr(), _ST)
+    return y
 
 
 def hessian_accum(H, X, nsamples_before: int, batch: int):

@@ -77,6 +77,8 @@ enum Opt : int {
     OPT_HESS_WIDE,
     OPT_HESS_BULK,
     OPT_HESS_PARTS,
+    OPT_GEMM_H16_BM,
+    OPT_LUT_DENSE_M,
     OPT_COUNT
 };
 long long opt_get(int id);
@@ -84,6 +86,11 @@ long long opt_get(int id);
 // raise a kernel's dynamic-LDS limit above the 64 KB default on the CURRENT device if that has not been done yet
 // (recorded per (device, kernel) under a mutex)
 int ensure_dynamic_lds(const void* func, size_t bytes);
+
+// dense fp16 / bf16 GEMM of the LUT forward's prefill path (gemm_h16.hip): y[M,N] = x[M,K] @ w[N,K]^T (+ bias) (+ addend)
+bool gemm_h16_supported(int64_t M, int64_t N, int64_t K);
+int gemm_h16(const void* x, const void* w, const void* bias, const float* addend, int dtype, int64_t M, int64_t N, int64_t K, void* y,
+             hipStream_t stream);
 
 // compute units of the CURRENT device (cached per device index; 0 on failure)
 int current_device_cus();

@@ -536,7 +536,8 @@ GemmPlan lut_gemm_plan(int64_t M, int64_t m, int64_t n) {
     // split in_features while the launch has fewer workgroups than CUs, every split keeping at least 8 stages (512 columns)
     const int force = (int)opt_get(OPT_LUT_GEMM_RM);  // developer switch: forced split factor
     int ks = 1;
-    while (ks < 8 && tiles * ks < 256 && nst / (2 * ks) >= 8) ks *= 2;
+    const int ncu = std::max(1, current_device_cus());
+    while (ks < 8 && tiles * ks < ncu && nst / (2 * ks) >= 8) ks *= 2;
     if (force > 0) ks = std::min(force, nst);
     p.st_per = (nst + ks - 1) / ks;
     p.KS = (nst + p.st_per - 1) / p.st_per;
@@ -566,7 +567,8 @@ static int launch_gemm_bits(const void* x, const uint32_t* qw, const void* lut, 
     // pipelined vs 103 us with the two-workgroups-per-CU kernel; 512 tiles (M = 4096) 175 vs 164; 896 tiles (14336 x 4096,
     // M = 2048) 310 vs 287; 1792 tiles (M = 4096) 556 vs 520: the pipelined kernel where a CU gets one tile, the other above
     const int64_t ntile = (int64_t)p.tiles_m * p.tiles_n;
-    const bool pipe_by_shape = ntile >= 224 && ntile < 448;
+    const int64_t ncu = std::max(1, current_device_cus());
+    const bool pipe_by_shape = 8 * ntile >= 7 * ncu && 4 * ntile < 7 * ncu;  // 224 <= tiles < 448 on the 256 CUs of an MI355X
     // the pipelined kernel addresses both operands through 32-bit buffer offsets (incl. one stage of look-ahead)
     const bool fits32 = ((int64_t)M + GBM) * n * 2 < (1ll << 31) && (int64_t)(n >> 5) * BITS * m * 4 < (1ll << 31);
     if (!fits32)

@@ -565,23 +565,38 @@ __global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_deco
     }
 }
 
+// The dense prefill path (gemm_h16.hip) dequantises the layer once per call: 64 output features per workgroup, their codebooks
+// in LDS as tbl[entry][feature] (the 64 lanes of a wave = 64 features: conflict-free), wave w takes the 32-column groups
+// g = 4 blockIdx.y + w, + 4 gridDim.y, ..; one coalesced word load per (group, bit plane), 8 lookups and ONE 16-byte store per octet.
 template <int BITS>
-__global__ __launch_bounds__(256) void lut_dequant_kernel(const uint32_t* __restrict__ qw, const void* __restrict__ lut,
-                                                          int dtype, int m, int n, uint16_t* __restrict__ Wq) {
-    // thread = (group g of 32 columns, output o); o fastest -> coalesced word reads; writes 64 B runs per thread
+__global__ __launch_bounds__(256) void lut_dequant_rows_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ lut,
+                                                               int m, int n, uint16_t* __restrict__ Wq) {
     constexpr int V = 1 << BITS;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint16_t tbl[V][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int o0 = blockIdx.x * 64;
+    for (int i = tid; i < 64 * V; i += 256) {
+        const int f = i / V, e = i % V;
+        tbl[e][f] = (o0 + f < m) ? lut[(int64_t)(o0 + f) * V + e] : (uint16_t)0;
+    }
+    __syncthreads();
+    const int o = o0 + lane;
+    if (o >= m) return;
     const int ngroups = n >> 5;
-    if (i >= (int64_t)ngroups * m) return;
-    const int o = (int)(i % m), g = (int)(i / m);
-    uint32_t w[BITS];
+    for (int g = blockIdx.y * 4 + wv; g < ngroups; g += gridDim.y * 4) {
+        uint32_t w[BITS];
 #pragma unroll
-    for (int b = 0; b < BITS; ++b) w[b] = qw[(int64_t)(g * BITS + b) * m + o];
-    const uint16_t* lr = static_cast<const uint16_t*>(lut) + (int64_t)o * V;
-    uint16_t* out = Wq + (int64_t)o * n + 32 * g;
-    (void)dtype;
+        for (int b = 0; b < BITS; ++b) w[b] = qw[(int64_t)(g * BITS + b) * m + o];
+        uint16_t* out = Wq + (int64_t)o * n + 32 * g;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) out[j] = lr[extract<BITS>(w, j)];
+        for (int oc = 0; oc < 4; ++oc) {
+            uint32_t d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[j] = (uint32_t)tbl[extract<BITS>(w, 8 * oc + 2 * j)][lane] | ((uint32_t)tbl[extract<BITS>(w, 8 * oc + 2 * j + 1)][lane] << 16);
+            *reinterpret_cast<uint4*>(out + 8 * oc) = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ Q, int m, int n, int bits,
@@ -677,13 +692,28 @@ int lut_gemm(const void* x, const uint32_t* qw, const void* lut, const void* bia
              int64_t m, int64_t n, int bits, void* y, float* partial, size_t partial_bytes, hipStream_t stream);
 size_t lut_gemm_workspace_bytes(int64_t M, int64_t m, int64_t n);
 
+// Prefill with many rows: dequantise the layer ONCE into the workspace and run the dense GEMM (gemm_h16.hip) -- every 256-row
+// tile of the fused kernel re-decodes the same weights.  Measured (MI355X, 4-bit fp16, round 4): 4096 x 4096 M = 4096 fused
+// 166 us, dense 116 + dequant; M = 2048 a tie; below, the dense tiles no longer fill the chip and the fused kernel's split of
+// in_features wins.  From >= 1024 rows on, when 128-row tiles give every CU at least one.
+static bool lut_dense_path(int64_t M, int64_t m, int64_t n) {
+    const long long thr = opt_get(OPT_LUT_DENSE_M);
+    if (thr == 0 || !gemm_h16_supported(M, m, n) || (n & 31) != 0) return false;
+    if (thr > 0) return M >= thr;
+    const int ncu = std::max(1, current_device_cus());
+    return M >= 1024 && ((M + 127) / 128) * ((m + 255) / 256) >= ncu;
+}
+
 }  // namespace ganq
 
 using namespace ganq;
 
 extern "C" size_t ganq_lut_linear_workspace_bytes(int64_t M, int64_t m, int64_t n, int bits) {
     if (M <= 0 || m <= 0 || n < 32) return 0;
-    if (M > LUT_MAX_M) return LUT_COUNTER_BYTES + lut_gemm_workspace_bytes(M, m, n);  // counters + split-K partial tiles
+    if (M > LUT_MAX_M) {  // counters + split-K partial tiles of the fused kernel, or the dequantised layer of the dense path
+        if (lut_dense_path(M, m, n)) return LUT_COUNTER_BYTES + align_up((size_t)m * (size_t)n * 2, 256);
+        return LUT_COUNTER_BYTES + lut_gemm_workspace_bytes(M, m, n);
+    }
     return lut_plan(M, m, n, bits).bytes;
 }
 
@@ -791,6 +821,22 @@ static int lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut
         if (!workspace || workspace_bytes < LUT_COUNTER_BYTES)
             return fail(-4, "ganq_lut_linear_fwd: workspace %zu B < required %zu B", workspace_bytes, LUT_COUNTER_BYTES);
         ProfScope gprof(KID_LUT_GEMM, gstream);
+        if (lut_dense_path(M, m, n)) {
+            const size_t need = LUT_COUNTER_BYTES + align_up((size_t)m * (size_t)n * 2, 256);
+            if (workspace_bytes < need) return fail(-4, "ganq_lut_linear_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
+            uint16_t* Wd = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + LUT_COUNTER_BYTES);
+            const uint32_t* qwp = reinterpret_cast<const uint32_t*>(qweight);
+            const uint16_t* lp = static_cast<const uint16_t*>(lut);
+            const int ngroups = (int)(n >> 5);
+            const int gx = (int)((m + 63) / 64);
+            const int gy = std::max(1, std::min((ngroups + 3) / 4, std::max(1, 4096 / gx)));
+            const dim3 grid((unsigned)gx, (unsigned)gy);
+            if (bits == 2) hipLaunchKernelGGL(lut_dequant_rows_kernel<2>, grid, dim3(256), 0, gstream, qwp, lp, (int)m, (int)n, Wd);
+            else if (bits == 3) hipLaunchKernelGGL(lut_dequant_rows_kernel<3>, grid, dim3(256), 0, gstream, qwp, lp, (int)m, (int)n, Wd);
+            else hipLaunchKernelGGL(lut_dequant_rows_kernel<4>, grid, dim3(256), 0, gstream, qwp, lp, (int)m, (int)n, Wd);
+            GANQ_LAUNCH_CHECK();
+            return gemm_h16(x, Wd, bias, addend, dtype, M, m, n, y, gstream);
+        }
         return lut_gemm(x, reinterpret_cast<const uint32_t*>(qweight), lut, bias, addend, dtype, M, m, n, bits, y,
                         reinterpret_cast<float*>(static_cast<char*>(workspace) + LUT_COUNTER_BYTES), workspace_bytes - LUT_COUNTER_BYTES,
                         gstream);
@@ -868,14 +914,19 @@ extern "C" int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dty
     if (rc) return rc;
     if (!qweight || !lut || !Wq_out) return fail(-3, "ganq_lut_dequant: null pointer");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int64_t total = (n >> 5) * m;
-    const dim3 grid((unsigned)((total + 255) / 256));
     const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
     uint16_t* out = static_cast<uint16_t*>(Wq_out);
     ProfScope prof(KID_LUT_GEMM, stream);
-    if (bits == 2) hipLaunchKernelGGL(lut_dequant_kernel<2>, grid, dim3(256), 0, stream, qw, lut, dtype, (int)m, (int)n, out);
-    else if (bits == 3) hipLaunchKernelGGL(lut_dequant_kernel<3>, grid, dim3(256), 0, stream, qw, lut, dtype, (int)m, (int)n, out);
-    else hipLaunchKernelGGL(lut_dequant_kernel<4>, grid, dim3(256), 0, stream, qw, lut, dtype, (int)m, (int)n, out);
+    {
+        const uint16_t* lp = static_cast<const uint16_t*>(lut);
+        const int ngroups = (int)(n >> 5);
+        const int gx = (int)((m + 63) / 64);
+        const int gy = std::max(1, std::min((ngroups + 3) / 4, std::max(1, 4096 / gx)));
+        const dim3 rgrid((unsigned)gx, (unsigned)gy);
+        if (bits == 2) hipLaunchKernelGGL(lut_dequant_rows_kernel<2>, rgrid, dim3(256), 0, stream, qw, lp, (int)m, (int)n, out);
+        else if (bits == 3) hipLaunchKernelGGL(lut_dequant_rows_kernel<3>, rgrid, dim3(256), 0, stream, qw, lp, (int)m, (int)n, out);
+        else hipLaunchKernelGGL(lut_dequant_rows_kernel<4>, rgrid, dim3(256), 0, stream, qw, lp, (int)m, (int)n, out);
+    }
     GANQ_LAUNCH_CHECK();
     return 0;
 }

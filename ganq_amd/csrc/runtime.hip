@@ -57,6 +57,8 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"GANQ_HESS_WIDE", 1},         // Hessian, staged groups: 256 x 128 tiles from 3072 in_features on (multiples of 256); 0: never, 2: whenever possible
     {"GANQ_HESS_BULK", -1},        // Hessian, developer: at most this many whole tiles (the others are cut); -1: as many as fill the CUs evenly
     {"GANQ_HESS_PARTS", 0},        // Hessian, developer: cut the tiles behind the bulk into exactly this many parts (0: as many as fill the free slots)
+    {"GANQ_GEMM_H16_BM", 0},       // dense GEMM of the LUT forward: force 128- / 256-row tiles (0: by tile count)
+    {"GANQ_LUT_DENSE_M", -1},      // LUT forward: from this many rows of x on, dequantise once + dense GEMM (-1: by shape; 0: never)
 };
 
 std::atomic<long long> g_opt[OPT_COUNT];

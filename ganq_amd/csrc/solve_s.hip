@@ -570,10 +570,11 @@ constexpr int DUO_MAX_TILES = 128;            // tiles with a helper (scratch is
 constexpr int DUO_TRIO_TILES = 80;            // ... with two helpers each (a third of the chip)
 constexpr int DUO_TW = 9;                     // flag words per tile: solved, ready[4] (helper -> tile), ready2[4] (second helper -> first)
 constexpr int DUO_CTRL_WORDS = 8 + DUO_MAX_TILES * DUO_TW;  // 8 ticket counters, then the tiles' flags
-// s_memtime ticks (100 MHz): 0.5 ms, about 60 column-panel steps (6-8 us each; 25 us for the last steps of n = 16384) -- long enough
-// for a helper that is resident but behind (it starts with a cold operand ring), short enough that a helper that is NOT resident
-// (another launch holds the CUs: side streams, a second process) costs a tile one wait of the order of the kernel's own time
-// instead of the 0.2 s of round 3.  The helpers' own waits are 16 x this.
+// s_memrealtime ticks (constant 100 MHz): 0.5 ms, about 60 column-panel steps (6-8 us each; 25 us for the last steps of n = 16384)
+// -- long enough for a helper that is resident but behind (it starts with a cold operand ring), short enough that a helper that is
+// NOT resident (another launch holds the CUs: side streams, a second process) costs a tile one wait of the order of the kernel's
+// own time.  (Rounds 1-3 counted 20 M ticks of s_memtime and called them 0.2 s; s_memtime ticks are shader cycles, so that was
+// ~9 ms -- still 10 x a whole launch.)  The helpers' own waits are 16 x this.
 constexpr unsigned long long DUO_TIMEOUT = 50ull * 1000;
 // number of source panels the tile's own waves keep, of the c = s - 1 panels of step s's chain (the nearest ones);
 // pol = xa | xb << 8 | xmin << 16 | cmin << 24:  x = max(xmin, xa c / 64 - xb) from c >= cmin on, everything below
@@ -1266,7 +1267,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                     // panel p was solved in step nb - p: wait until the tile has announced that step
                     int seen = 0;
                     if (lane == 0) {
-                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                         for (;;) {
                             const uint32_t v = __hip_atomic_load(solved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)(nb - need)) {
@@ -1275,7 +1276,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                             }
                             // every spin is bounded: a tile that has not announced a panel for 16 x DUO_TIMEOUT is not coming
                             // (it gave up on this helper long before); the four waves read the same flag and leave together
-                            if (__builtin_amdgcn_s_memtime() - t0 > 16 * DUO_TIMEOUT) break;
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > 16 * DUO_TIMEOUT) break;
                             __builtin_amdgcn_s_sleep(8);
                         }
                     }
@@ -1294,14 +1295,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                 if (hstage == 1 && h2 > 0) {  // first helper of a trio: continue from the second helper's accumulators
                     int ok = 0;
                     if (lane == 0) {
-                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                         for (;;) {
                             const uint32_t v = __hip_atomic_load(upstream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)s) {
                                 ok = 1;
                                 break;
                             }
-                            if (__builtin_amdgcn_s_memtime() - t0 > 16 * DUO_TIMEOUT) break;
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > 16 * DUO_TIMEOUT) break;
                             __builtin_amdgcn_s_sleep(4);
                         }
                     }
@@ -1366,14 +1367,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_s_kernel(const float* __r
                         int ok = 0;
                         if (lane == 0) {
                             const uint32_t* ready = ctrl + 8 + DUO_TW * tile + 1 + gw;
-                            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                             for (;;) {
                                 const uint32_t v = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 if ((v ^ tag) < 1024u && (v & 1023u) >= (uint32_t)s) {
                                     ok = 1;
                                     break;
                                 }
-                                if (__builtin_amdgcn_s_memtime() - t0 > DUO_TIMEOUT) break;
+                                if (__builtin_amdgcn_s_memrealtime() - t0 > DUO_TIMEOUT) break;
                                 __builtin_amdgcn_s_sleep(4);
                             }
                         }

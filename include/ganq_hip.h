@@ -56,6 +56,11 @@ int ganq_debug_div_check(uint64_t count, uint32_t seed, unsigned long long* mism
  * 31-bit fixed-point H it is formed with.  Allocates its own scratch and synchronises the stream. */
 int ganq_debug_wh_product(const float* W, const float* H, int64_t m, int64_t n, double* WH_out, double* Hfixed_out, void* stream);
 
+/* Developer / tests: the dense fp16 / bf16 GEMM the LUT forward uses from ~1024 rows of x on (csrc/gemm_h16.hip), on its own:
+ * y [M,N] = x [M,K] @ w [N,K]^T (+ bias [N]) (+ addend [M,N] fp32), dtype 0 = fp16, 1 = bf16; K a multiple of 64, N of 4. */
+int ganq_debug_gemm_h16(const void* x, const void* w, const void* bias, const float* addend, int dtype, int64_t M, int64_t N,
+                        int64_t K, void* y, void* stream);
+
 /* ---- a1: Hessian accumulation (gptq.py:96-131 process_batch) --------------------------------
  * One calibration batch: X [rows, n] fp16 or bf16 (dtype: 0 = fp16, 1 = bf16), `batch` = number
  * of sequences in it (gptq.py:104), nsamples_before = sequences accumulated so far.

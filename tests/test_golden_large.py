@@ -30,7 +30,7 @@ _cache = {}
 #   h768x768_b4_k10 [0,1,2,0,1,1,0,0,0,0]; h1024x4096_b3_k2, l64x8192_b4_k3, l32x14336_b4_k2, l32x14336_b3_k2: see HIP_LEAVING
 HIP_LEAVING = {
     "h4096x4096_b4_k2": (40, 40), "h3072x768_b4_k10": (8, 22), "h768x3072_b4_k10": (16, 40), "h768x768_b4_k10": (4, 10),
-    "h1024x4096_b3_k2": (4, 4), "l64x8192_b4_k3": (1, 2), "l32x14336_b4_k2": (1, 2), "l32x14336_b3_k2": (1, 2),
+    "h1024x4096_b3_k2": (12, 12), "l64x8192_b4_k3": (2, 2), "l32x14336_b4_k2": (2, 2), "l32x14336_b3_k2": (2, 2),
 }
 # the CPU oracle, free-running: rows leaving (the small traced cases: none); measured l32x14336_b4_k2 [0, 1]
 ORACLE_LEAVING = {"l64x8192_b4_k3": (1, 1), "l32x14336_b4_k2": (1, 2), "l32x14336_b3_k2": (1, 1)}
