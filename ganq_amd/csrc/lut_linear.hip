@@ -565,14 +565,19 @@ __global__ __launch_bounds__(1024, (RT == 1 && BITS != 3) ? 8 : 4) void lut_deco
     }
 }
 
-// The dense prefill path (gemm_h16.hip) dequantises the layer once per call: 64 output features per workgroup, their codebooks
-// in LDS as tbl[entry][feature] (the 64 lanes of a wave = 64 features: conflict-free), wave w takes the 32-column groups
-// g = 4 blockIdx.y + w, + 4 gridDim.y, ..; one coalesced word load per (group, bit plane), 8 lookups and ONE 16-byte store per octet.
+// The dense prefill path (gemm_h16.hip) dequantises the layer once per call.  64 output features per workgroup, their codebooks
+// in LDS as tbl[entry][feature] (the 64 lanes of a wave = 64 features: conflict-free); a wave takes 64 columns (two 32-column
+// groups) of its 64 features per step: coalesced word loads (lane = feature), 64 lookups, and the 128 bytes of every feature go
+// through an LDS tile (16-byte slots XOR-swizzled with (feature >> 1) & 7: conflict-free both ways) so that the global stores are
+// WHOLE 128-byte lines -- 8 lanes per feature, 8 features per instruction.  (Round 4's first version stored 16 bytes per lane
+// at a stride of one row, 64 lines per instruction: 17 us per 4096 x 4096 against 8 now.)  An odd last group of 32 columns is
+// stored the slow way.
 template <int BITS>
 __global__ __launch_bounds__(256) void lut_dequant_rows_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ lut,
                                                                int m, int n, uint16_t* __restrict__ Wq) {
     constexpr int V = 1 << BITS;
     __shared__ uint16_t tbl[V][64];
+    __shared__ __align__(16) char tile[4][64 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int o0 = blockIdx.x * 64;
     for (int i = tid; i < 64 * V; i += 256) {
@@ -580,10 +585,39 @@ __global__ __launch_bounds__(256) void lut_dequant_rows_kernel(const uint32_t* _
         tbl[e][f] = (o0 + f < m) ? lut[(int64_t)(o0 + f) * V + e] : (uint16_t)0;
     }
     __syncthreads();
-    const int o = o0 + lane;
-    if (o >= m) return;
-    const int ngroups = n >> 5;
-    for (int g = blockIdx.y * 4 + wv; g < ngroups; g += gridDim.y * 4) {
+    const int o = min(o0 + lane, m - 1);  // (lanes past the last feature decode a copy; they store nothing)
+    const int npairs = n >> 6;
+    char* my = tile[wv];
+    const int sw = (lane >> 1) & 7;
+    for (int gp = blockIdx.y * 4 + wv; gp < npairs; gp += gridDim.y * 4) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int g = 2 * gp + half;
+            uint32_t w[BITS];
+#pragma unroll
+            for (int b = 0; b < BITS; ++b) w[b] = qw[(int64_t)(g * BITS + b) * m + o];
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc) {
+                uint32_t d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    d[j] = (uint32_t)tbl[extract<BITS>(w, 8 * oc + 2 * j)][lane] | ((uint32_t)tbl[extract<BITS>(w, 8 * oc + 2 * j + 1)][lane] << 16);
+                *reinterpret_cast<uint4*>(my + lane * 128 + (((4 * half + oc) ^ sw) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = 8 * i + (lane >> 3), slot = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(my + f * 128 + ((slot ^ ((f >> 1) & 7)) << 4));
+            if (o0 + f < m) *reinterpret_cast<uint4*>(Wq + (int64_t)(o0 + f) * n + 64 * gp + 8 * slot) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if ((n & 63) != 0 && blockIdx.y == 0 && wv == 0 && o0 + lane < m) {  // the odd last group of 32 columns
+        const int g = (n >> 5) - 1;
         uint32_t w[BITS];
 #pragma unroll
         for (int b = 0; b < BITS; ++b) w[b] = qw[(int64_t)(g * BITS + b) * m + o];
@@ -695,13 +729,13 @@ size_t lut_gemm_workspace_bytes(int64_t M, int64_t m, int64_t n);
 // Prefill with many rows: dequantise the layer ONCE into the workspace and run the dense GEMM (gemm_h16.hip) -- every 256-row
 // tile of the fused kernel re-decodes the same weights.  Measured (MI355X, 4-bit fp16, round 4): 4096 x 4096 M = 4096 fused
 // 166 us, dense 116 + dequant; M = 2048 a tie; below, the dense tiles no longer fill the chip and the fused kernel's split of
-// in_features wins.  From >= 1024 rows on, when 128-row tiles give every CU at least one.
+// in_features wins.  From >= 1024 rows on, when 256-row tiles give (nearly) every CU one.
 static bool lut_dense_path(int64_t M, int64_t m, int64_t n) {
     const long long thr = opt_get(OPT_LUT_DENSE_M);
     if (thr == 0 || !gemm_h16_supported(M, m, n) || (n & 31) != 0) return false;
     if (thr > 0) return M >= thr;
     const int ncu = std::max(1, current_device_cus());
-    return M >= 1024 && ((M + 127) / 128) * ((m + 255) / 256) >= ncu;
+    return M >= 1024 && 8 * ((M + 255) / 256) * ((m + 255) / 256) >= 7 * ncu;  // 256-row tiles (nearly) fill the chip
 }
 
 }  // namespace ganq
@@ -827,9 +861,9 @@ static int lut_linear_fwd(const void* x, const int32_t* qweight, const void* lut
             uint16_t* Wd = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + LUT_COUNTER_BYTES);
             const uint32_t* qwp = reinterpret_cast<const uint32_t*>(qweight);
             const uint16_t* lp = static_cast<const uint16_t*>(lut);
-            const int ngroups = (int)(n >> 5);
+            const int npairs = (int)(n >> 6);
             const int gx = (int)((m + 63) / 64);
-            const int gy = std::max(1, std::min((ngroups + 3) / 4, std::max(1, 4096 / gx)));
+            const int gy = std::max(1, std::min((npairs + 3) / 4, std::max(1, 2048 / gx)));
             const dim3 grid((unsigned)gx, (unsigned)gy);
             if (bits == 2) hipLaunchKernelGGL(lut_dequant_rows_kernel<2>, grid, dim3(256), 0, gstream, qwp, lp, (int)m, (int)n, Wd);
             else if (bits == 3) hipLaunchKernelGGL(lut_dequant_rows_kernel<3>, grid, dim3(256), 0, gstream, qwp, lp, (int)m, (int)n, Wd);
@@ -919,9 +953,9 @@ extern "C" int ganq_lut_dequant(const int32_t* qweight, const void* lut, int dty
     ProfScope prof(KID_LUT_GEMM, stream);
     {
         const uint16_t* lp = static_cast<const uint16_t*>(lut);
-        const int ngroups = (int)(n >> 5);
+        const int npairs = (int)(n >> 6);
         const int gx = (int)((m + 63) / 64);
-        const int gy = std::max(1, std::min((ngroups + 3) / 4, std::max(1, 4096 / gx)));
+        const int gy = std::max(1, std::min((npairs + 3) / 4, std::max(1, 2048 / gx)));
         const dim3 rgrid((unsigned)gx, (unsigned)gy);
         if (bits == 2) hipLaunchKernelGGL(lut_dequant_rows_kernel<2>, rgrid, dim3(256), 0, stream, qw, lp, (int)m, (int)n, out);
         else if (bits == 3) hipLaunchKernelGGL(lut_dequant_rows_kernel<3>, rgrid, dim3(256), 0, stream, qw, lp, (int)m, (int)n, out);

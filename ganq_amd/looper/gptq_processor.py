@@ -71,7 +71,7 @@ class GPTQProcessor:
         self._results[module.full_name] = {
             "scale": scale, "zero": zero, "g_idx": g_idx,
             "ganq_q": g.ganq_indices, "ganq_lut": g.ganq_codebook, "bits": g.qcfg.bits,
-            "ganq_outliers": getattr(g, "ganq_outliers", None),
+            "ganq_outliers": getattr(g, "ganq_outliers", None), "avg_loss": avg_loss,
         }
         module.state.update({"wq": wq, "ganq_q": g.ganq_indices, "ganq_lut": g.ganq_codebook,
                              "quant_time": time.time() - t0, "avg_loss": avg_loss,
