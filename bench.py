@@ -251,6 +251,7 @@ def make_sharded_quantize(cap, dist):
         q.quantizer.configure(perchannel=True)
         q.H, q.nsamples = cap["H_raw"].clone(), cap["nsamples"]
         q.row_dist, q.time_collectives = dist, timing
+        q.force_row_path = True  # also at world = 1: the same code path and phase timers for every N
         q.fwd_counter = 1
         q.quantize()
         return q
@@ -445,7 +446,18 @@ def lut_forward_report():
         rows.append(per_shape[shape])
     lut_us = sum(per_shape[s]["lut_us"] for s in layer.values())
     f16_us = sum(per_shape[s]["torch_fp16_us"] for s in layer.values())
-    return {"what": "y = x @ dequant(qweight, lut)^T, 4-bit, fp16 activations; device us per call from HIP-graph replays of 200 calls; "
+    # prefill (M >= 2048): the LUT forward (round 4: dequantise once + the hand-written dense GEMM of csrc/gemm_h16.hip from
+    # ~1024 rows on, the fused LUT-dequant GEMM below) against the library fp16 GEMM on the pre-dequantised weight and against
+    # dequant + library
+    import bench_lut_gemm as bg
+
+    gemm = []
+    for (m, n) in [(4096, 4096), (14336, 4096), (4096, 14336)]:
+        for M in (2048, 4096):
+            r = bg.bench(m, n, M)
+            gemm.append({k: r[k] for k in ("out_x_in", "M", "lut_gemm_us", "lib_fp16_gemm_us", "dequant_plus_lib_us", "lut_gemm_TFLOPs",
+                                           "lib_TFLOPs", "vs_lib", "vs_dequant_plus_lib")})
+    return {"gemm": gemm, "what": "y = x @ dequant(qweight, lut)^T, 4-bit, fp16 activations; device us per call from HIP-graph replays of 200 calls; "
                     "cold = a ring of layers larger than the 256 MB Infinity Cache", "peak_GBs": HBM_PEAK_GBS, "shapes": rows,
             "llama32_1b_decoder_layer_M1_cold": {"linears": 7, "lut_us": round(lut_us, 2), "torch_fp16_us": round(f16_us, 2),
                                                  "speedup": round(f16_us / lut_us, 2)}}
@@ -561,21 +573,25 @@ def main():
     row_sharded = phases = None
     if args.mode == "rows":
         phases = rows_phases(cap, dist)
-    elif dist.world > 1:
-        gdist.broadcast_tensor(cap["lin"].weight.data, 0)
-        gdist.broadcast_tensor(cap["H_raw"], 0)
+    else:  # every N (also 1): the complete row-sharded quantize() of rank 0's layer, with its phases
+        if dist.world > 1:
+            gdist.broadcast_tensor(cap["lin"].weight.data, 0)
+            gdist.broadcast_tensor(cap["H_raw"], 0)
         sharded_step = make_sharded_quantize(cap, dist)
         sharded_step()
         phases = rows_phases(cap, dist)
         torch.cuda.synchronize()
-        td.barrier()
+        if dist.world > 1:
+            td.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             sharded_step()
         torch.cuda.synchronize()
-        td.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if td.get_backend() != "gloo" else "cpu")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
+        if dist.world > 1:
+            td.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if (dist.world > 1 and td.get_backend() != "gloo") else "cpu")
+        if dist.world > 1:
+            td.all_reduce(t, op=td.ReduceOp.MAX)
         row_sharded = {"what": "ONE 4096x4096 layer, complete quantize() on the reduced Hessian (prologue replicated; k-means + fused "
                                "loop on each rank's row slice; exchange of row losses / chosen rows), rows split over the GPUs: strong scaling",
                        "columns_per_s": round(args.steps * args.n / float(t), 2), "ms_per_layer": round(float(t) / args.steps * 1e3, 3),

@@ -298,8 +298,26 @@ class _Turn:
         return False
 
 
+def _raise_together(err: Optional[BaseException], what: str, device, dist: Dist) -> None:
+    """one int per rank, MAX-reduced: a rank-local failure (`err`) raises on EVERY rank instead of leaving the others in the
+    next collective until the RCCL timeout"""
+    flag = torch.tensor([0 if err is None else 1 + dist.rank], dtype=torch.int64, device=device)
+    if dist.world > 1:
+        if td.get_backend() == "gloo" and flag.is_cuda:
+            host = flag.cpu()
+            td.all_reduce(host, op=td.ReduceOp.MAX)
+            flag = host
+        else:
+            td.all_reduce(flag, op=td.ReduceOp.MAX)
+    bad = int(flag)
+    if err is not None:
+        raise err
+    if bad:
+        raise RuntimeError(f"{what}: rank {bad - 1} failed in its local part; every rank stops")
+
+
 def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: float = -1.0, dist: Optional[Dist] = None,
-                          solver=None, t0_fn=None, stats: Optional[dict] = None, turn=None):
+                          solver=None, t0_fn=None, stats: Optional[dict] = None, turn=None, V: Optional[int] = None):
     """ganq.py:501-634 with the rows of W split over the ranks.  Every rank passes the FULL W (replicated) and gets the
     FULL (T_best, Q, dists, best_k) back.  T0: the full initial codebook (replicated), or None with
     `t0_fn(W_rows) -> T0_rows`: then the codebook initialisation (ganq.py:423-438, rows are independent) is sharded as
@@ -312,7 +330,9 @@ def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: floa
     chosen codebook rows and one of the index rows.
     stats: optional dict; with stats["timing"] set, "kmeans_s" / "loop_s" / "collective_s" are added up in it.
     turn: optional context manager (CollectiveTurns.turn(i)) entered around the exchange, when the modules of a group run
-    their local parts concurrently."""
+    their local parts concurrently.
+    V: codebook width (2^bits); needed by a rank that owns no rows when T0 is None.
+    A failure in a rank's local part (k-means, fused loop) is exchanged before the first all-gather: every rank raises."""
     import contextlib
 
     dist = dist or Dist.current()
@@ -322,24 +342,31 @@ def run_layer_row_sharded(W, H, L, T0, K: int, alias_q: bool = True, rcond: floa
     # 128-row alignment keeps the per-128-row decisions of the W @ H kernel identical to the unsharded run
     slices = row_slices(m, dist.world, align=128 if m >= 128 * dist.world else 16)
     lo, hi = slices[dist.rank]
-    V = None if T0 is None else T0.shape[1]
-    if hi > lo:
-        W_loc = W[lo:hi].contiguous()
-        with timer("kmeans_s"):
-            T0_loc = T0[lo:hi].contiguous() if T0 is not None else t0_fn(W_loc)
-        V = T0_loc.shape[1]
-        with timer("loop_s"):
-            rec = solver.run_layer_rows(W_loc, H, L, T0_loc, K, alias_q, rcond)
-        loss_loc, T_all, Q_last, Q_all = rec["loss_rows_all"], rec["T_all"], rec["Q_last"], rec["Q_all"]
-    else:
-        if V is None:  # a rank without rows still needs the codebook width: cluster one row
-            V = t0_fn(W[:1].contiguous()).shape[1]
-        loss_loc = torch.zeros((K, 0), dtype=torch.float64, device=W.device)
-        T_all = torch.zeros((K, 0, V), dtype=torch.float32, device=W.device)
-        Q_last = torch.zeros((0, n), dtype=torch.uint8, device=W.device)
-        Q_all = None if alias_q else torch.zeros((K, 0, n), dtype=torch.uint8, device=W.device)
+    if T0 is not None:
+        V = T0.shape[1]
+    err = None
+    loss_loc = T_all = Q_last = Q_all = None
+    try:
+        if hi > lo:
+            W_loc = W[lo:hi].contiguous()
+            with timer("kmeans_s"):
+                T0_loc = T0[lo:hi].contiguous() if T0 is not None else t0_fn(W_loc)
+            V = T0_loc.shape[1]
+            with timer("loop_s"):
+                rec = solver.run_layer_rows(W_loc, H, L, T0_loc, K, alias_q, rcond)
+            loss_loc, T_all, Q_last, Q_all = rec["loss_rows_all"], rec["T_all"], rec["Q_last"], rec["Q_all"]
+        else:
+            if V is None:
+                raise ValueError("run_layer_row_sharded: a rank without rows needs the codebook width: pass V= (2 ** bits) or T0")
+            loss_loc = torch.zeros((K, 0), dtype=torch.float64, device=W.device)
+            T_all = torch.zeros((K, 0, V), dtype=torch.float32, device=W.device)
+            Q_last = torch.zeros((0, n), dtype=torch.uint8, device=W.device)
+            Q_all = None if alias_q else torch.zeros((K, 0, n), dtype=torch.uint8, device=W.device)
+    except BaseException as e:  # exchanged below, inside this module's turn (the collectives keep their order on every rank)
+        err = e
     with (turn if turn is not None else contextlib.nullcontext()):
         with timer("collective_s"):
+            _raise_together(err, "run_layer_row_sharded", W.device, dist)
             loss_all = allgather_rows(loss_loc, slices, 1, dist)  # K x m doubles: the only exchange the decision needs
         dists, best_k_t = solver.select_best(loss_all)
         best_k = int(best_k_t)
@@ -388,16 +415,27 @@ def broadcast_calibration_batch(x: Optional[torch.Tensor], owner: int, dist: Dis
     module was not invoked for this batch: then None comes back everywhere)."""
     dev = dist.device or torch.device("cpu")
     codes = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
-    meta = torch.zeros(6, dtype=torch.int64, device=dev)
+    # meta: state (0 none, 1 tensor follows, -1 the owner cannot send this batch), ndim, up to 4 dims, dtype code
+    meta = torch.zeros(7, dtype=torch.int64, device=dev)
+    problem = None
     if dist.rank == owner and x is not None:
-        shp = list(x.shape)
-        meta[0], meta[1], meta[5] = 1, len(shp), codes[x.dtype]
-        for i, d in enumerate(shp[:3]):
-            meta[2 + i] = d
+        if x.dtype not in codes:
+            problem = f"activations of dtype {x.dtype} (fp16 / bf16 / fp32 are exchanged)"
+        elif not 1 <= x.dim() <= 4:
+            problem = f"activations with {x.dim()} dimensions"
+        if problem is None:
+            shp = list(x.shape)
+            meta[0], meta[1], meta[6] = 1, len(shp), codes[x.dtype]
+            for i, d in enumerate(shp):
+                meta[2 + i] = d
+        else:
+            meta[0] = -1  # every rank raises together instead of the receivers waiting in the broadcast
     broadcast_tensor(meta, owner)
+    if int(meta[0]) < 0:
+        raise ValueError("broadcast_calibration_batch: rank %d cannot send its batch%s" % (owner, f": {problem}" if problem else ""))
     if int(meta[0]) == 0:
         return None
     shape = tuple(int(v) for v in meta[2:2 + int(meta[1])])
-    dtype = {v: k for k, v in codes.items()}[int(meta[5])]
+    dtype = {v: k for k, v in codes.items()}[int(meta[6])]
     buf = x.contiguous() if dist.rank == owner else torch.empty(shape, dtype=dtype, device=dev)
     return broadcast_tensor(buf, owner)

@@ -73,7 +73,7 @@ class GANQ(GPTQ):
             sparse = (rowptr, cols, vals)
         alias = bool(getattr(self.qcfg, "ganq_reference_q_alias", True))
         rd = self.row_dist
-        if rd is not None and rd.world > 1:
+        if rd is not None and (rd.world > 1 or getattr(self, "force_row_path", False)):  # (forced at world 1: bench phase timing)
             # rows of W are independent in the codebook initialisation, the S-solve and the T-update; only best-of-K
             # looks at all of them: each rank clusters and iterates its own rows, one exchange of K x m row losses
             # decides, one all-gather each brings the chosen codebook rows and the indices to every rank
@@ -82,7 +82,7 @@ class GANQ(GPTQ):
             stats = {"timing": bool(getattr(self, "time_collectives", False))}
             T, Q, dists, best_k = gdist.run_layer_row_sharded(
                 W, self.Xxt_damped, self.L, None, self.iterations, alias_q=alias, dist=rd, stats=stats,
-                turn=getattr(self, "_collective_turn", None), solver=gdist.HipSolver(helpers=self.solve_helpers),
+                turn=getattr(self, "_collective_turn", None), solver=gdist.HipSolver(helpers=self.solve_helpers), V=V,
                 t0_fn=lambda W_rows: self._initialize_codebook_kmeans(W_rows, Hinv, num_bits, W.device))
             self.ganq_stats.update({k: v for k, v in stats.items() if k != "timing"})
         else:

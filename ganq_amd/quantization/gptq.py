@@ -29,8 +29,18 @@ _SIDE_STREAMS = {}
 # Hessian staging buffers alive per device (see GPTQ.__init__): each is stage_tokens x in_features activations (134 MB at
 # n = 4096, 470 MB at 14336).  A group of E mixture-of-experts modules would hold E of them through its forward passes; beyond
 # this many live buffers on a device a task accumulates batch by batch instead (same H up to fp32 summation order).
-_STAGE_LIVE = {}
+_STAGE_LIVE = {}   # device index -> weakref.WeakSet of the live buffers' holders: a task that is dropped without free() /
+                   # end_of_calibration() (an exception in a forward pass, an abandoned looper) gives its slot back when it dies
 STAGE_MAX_LIVE = 8
+
+
+class _StageBuffer:
+    """holder of one staging tensor (torch tensors are not hashable members of a WeakSet by identity semantics we want)"""
+
+    __slots__ = ("tensor", "__weakref__")
+
+    def __init__(self, tensor):
+        self.tensor = tensor
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -74,6 +84,7 @@ class GPTQ:
         # eight times longer per tile.  0 turns the staging off.
         self.hessian_stage_tokens = int(getattr(self.qcfg, "ganq_hessian_stage_tokens", 16384) or 0)
         self._stage = None        # [capacity, columns] in the activations' dtype
+        self._stage_holder = None
         self._stage_rows = 0
         self._stage_seqs = 0
 
@@ -133,19 +144,26 @@ class GPTQ:
 
     def _stage_acquire(self, dtype) -> bool:
         """allocate this task's staging buffer unless the device already holds STAGE_MAX_LIVE of them"""
+        import weakref
+
         self._stage_release()
         key = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        if _STAGE_LIVE.get(key, 0) >= STAGE_MAX_LIVE:
+        live = _STAGE_LIVE.setdefault(key, weakref.WeakSet())
+        if len(live) >= STAGE_MAX_LIVE:
             return False
-        self._stage = torch.empty((self.hessian_stage_tokens, self.columns), dtype=dtype, device=self.device)
-        _STAGE_LIVE[key] = _STAGE_LIVE.get(key, 0) + 1
+        self._stage_holder = _StageBuffer(torch.empty((self.hessian_stage_tokens, self.columns), dtype=dtype, device=self.device))
+        self._stage = self._stage_holder.tensor
+        live.add(self._stage_holder)
         return True
 
     def _stage_release(self):
         if self._stage is not None:
             key = self.device.index if self.device.index is not None else torch.cuda.current_device()
-            _STAGE_LIVE[key] = max(0, _STAGE_LIVE.get(key, 0) - 1)
+            live = _STAGE_LIVE.get(key)
+            if live is not None and self._stage_holder is not None:
+                live.discard(self._stage_holder)
             self._stage = None
+            self._stage_holder = None
 
     def end_of_calibration(self):
         """The looper calls this when the forward passes of the module's group are over: the staged batches go to the

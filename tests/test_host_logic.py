@@ -146,6 +146,94 @@ def test_row_sharded_two_ranks_gloo(name, alias):
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
+def _worker4(rank, world, port, mode, out_q):
+    """world-4 cases: ragged row slices with a rank that owns NO rows, sharded k-means (t0_fn), failure propagation"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import datetime
+
+    import torch.distributed as td
+
+    td.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from oracle import c_oracle
+
+        c_oracle.set_num_threads(1)
+        dist = gdist.Dist(rank, world, torch.device("cpu"))
+        g = _golden("c64x256_b4")   # 64 rows: 4 tiles of 16 -> with 40 rows kept, slices 16 + 16 + 8 + 0
+        W, H, L = (torch.from_numpy(g[k]) for k in ("W_perm", "Xxt_damped", "L"))
+        rows = 40
+        W = W[:rows].contiguous()
+        V, K = int(g["T"].shape[2]), int(g["K"])
+
+        def t0_fn(W_rows):
+            if mode == "fail" and rank == 1:
+                raise RuntimeError("injected failure in the local part of rank 1")
+            return torch.from_numpy(c_oracle.kmeans_init(W_rows.numpy(), None, V))
+
+        if mode == "badbatch":
+            x = torch.zeros(2, 3, dtype=torch.float64) if rank == 0 else None  # a dtype the exchange does not carry
+            try:
+                gdist.broadcast_calibration_batch(x, 0, dist)
+                out_q.put((rank, "no error"))
+            except ValueError as e:
+                out_q.put((rank, "ValueError: " + str(e)))
+            return
+        try:
+            T, Q, dists, best_k = gdist.run_layer_row_sharded(W, H, L, None, K, alias_q=True, dist=dist, solver=OracleSolver(),
+                                                              t0_fn=t0_fn, V=V)
+            out_q.put((rank, T.numpy(), Q.numpy(), dists.numpy(), best_k, gdist.row_slices(rows, world, align=16)))
+        except RuntimeError as e:
+            out_q.put((rank, "RuntimeError: " + str(e)))
+    finally:
+        td.destroy_process_group()
+
+
+def _run4(mode):
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = 29850 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, mode, out_q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted((out_q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_row_sharded_four_ranks_zero_row_rank_gloo():
+    """40 rows over 4 ranks in 16-row tiles: 16 + 16 + 8 + 0 -- the fourth rank owns nothing, clusters nothing (V is passed in)
+    and still takes part in every collective; the initial codebook is clustered per slice and never exchanged; every rank ends
+    with the result of the unsharded oracle run"""
+    from oracle import c_oracle
+
+    res = _run4("ok")
+    g = _golden("c64x256_b4")
+    W, H, L = g["W_perm"][:40].copy(), g["Xxt_damped"], g["L"]
+    V, K = int(g["T"].shape[2]), int(g["K"])
+    T0 = c_oracle.kmeans_init(W, None, V)
+    To, Qo, do, bko = c_oracle.run_layer(W, H, L, T0, K)
+    for rank, T, Q, dists, best_k, slices in res:
+        assert slices == [(0, 16), (16, 32), (32, 40), (40, 40)]
+        assert best_k == bko and np.array_equal(Q, Qo) and np.array_equal(T, To) and np.allclose(dists, do, rtol=1e-12)
+
+
+def test_row_sharded_failure_on_one_rank_raises_on_all_gloo():
+    """a rank whose local part fails (here: its k-means) must not leave the others waiting in the all-gather: the status
+    exchange in front of the first collective makes EVERY rank raise"""
+    res = _run4("fail")
+    assert all(isinstance(r[1], str) and r[1].startswith("RuntimeError") for r in res), res
+    assert "injected failure" in res[1][1] and all("rank 1 failed" in r[1] for i, r in enumerate(res) if i != 1)
+
+
+def test_broadcast_calibration_batch_bad_dtype_raises_on_all_gloo():
+    res = _run4("badbatch")
+    assert all(r[1].startswith("ValueError") and "cannot send" in r[1] for r in res), res
+
+
 def test_backend_registration_selects_the_lut_layer():
     """BACKEND / FORMAT_DICT / select_quant_linear as code (utils/importer.py:45-68,157-262 of the reference)"""
     from ganq_amd.nn_modules.backend import AUTO_SELECT_BACKEND_ORDER, BACKEND, FORMAT_DICT, select_quant_linear
