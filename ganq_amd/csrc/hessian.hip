@@ -373,6 +373,29 @@ __global__ __launch_bounds__(256 * MH, MH == 1 ? 3 : 4) void hessian_sk_kernel(f
     }
 }
 
+// The parts of the cut tiles, summed IN TOKEN ORDER by the whole chip (round 4): rest x parts partial tiles of 64 / 128 KB -- 32 MB
+// at n = 4096 -- used to be read by `rest` = 16 workgroups, one per tile, part after part: 95 us of a 447 us group of 16384 tokens
+// (rocprofv3, round 3).  Here every thread owns 8 floats of one tile (two float4 of its 2048-float slice) and adds the parts
+// p = 1, 2, .. onto part 0 in place; hessian_fix_kernel then finishes the tile from that one part.  Same additions in the same
+// order ((p0 + p1) + p2 ...), one element = one thread: the same bits.
+constexpr int PRESUM_SLICE = 2048;  // floats per workgroup: 256 threads x 2 float4
+template <int MH>
+__global__ __launch_bounds__(256) void hessian_presum_kernel(int rest, int parts, float* __restrict__ partial) {
+    using Shape = HessShape<MH>;
+    constexpr int SLICES = Shape::PART_FLOATS / PRESUM_SLICE;
+    const int j = (int)blockIdx.x / SLICES, sl = (int)blockIdx.x % SLICES;
+    float4* base = reinterpret_cast<float4*>(partial + (int64_t)j * Shape::PART_FLOATS + (int64_t)sl * PRESUM_SLICE) + threadIdx.x;
+    const int64_t stride4 = (int64_t)rest * Shape::PART_FLOATS / 4;  // one part further (float4 units)
+    float4 a0 = base[0], a1 = base[256];
+    for (int p = 1; p < parts; ++p) {
+        const float4 b0 = base[p * stride4], b1 = base[p * stride4 + 256];
+        a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+        a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+    }
+    base[0] = a0;
+    base[256] = a1;
+}
+
 // one workgroup per cut tile: the sum of its parts in token order, then the same finish as everywhere
 template <int MH>
 __global__ __launch_bounds__(256 * MH) void hessian_fix_kernel(float* __restrict__ H, int n, float decay, float scale,
@@ -544,9 +567,16 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
         else
             hipLaunchKernelGGL((hessian_sk_kernel<false, MH>), dim3(grid), dim3(Shape::NT), 0, stream, H, Xp, (int)rows, (int)n, decay, scale, ord,
                                bulk, rest, part_slabs, part);
-        if (rest > 0)
+        if (rest > 0) {
+            int fix_parts = parts;
+            if (parts > 2) {  // the parts summed by the whole chip first (hessian_presum_kernel)
+                hipLaunchKernelGGL(hessian_presum_kernel<MH>, dim3((unsigned)(rest * (Shape::PART_FLOATS / PRESUM_SLICE))), dim3(256), 0, stream, rest,
+                                   parts, part);
+                fix_parts = 1;
+            }
             hipLaunchKernelGGL(hessian_fix_kernel<MH>, dim3((unsigned)rest), dim3(Shape::NT), 0, stream, H, (int)n, decay, scale, ord, bulk, rest,
-                               parts, part);
+                               fix_parts, part);
+        }
         GANQ_LAUNCH_CHECK();
         return 1;
     };
