@@ -72,6 +72,8 @@ class GPTQProcessor:
             "scale": scale, "zero": zero, "g_idx": g_idx,
             "ganq_q": g.ganq_indices, "ganq_lut": g.ganq_codebook, "bits": g.qcfg.bits,
             "ganq_outliers": getattr(g, "ganq_outliers", None), "avg_loss": avg_loss,
+            # a convolution keeps its dequantised weight (there is no LUT layer for it): finalize() does not pack it
+            "packable": not isinstance(module.module, nn.Conv2d),
         }
         module.state.update({"wq": wq, "ganq_q": g.ganq_indices, "ganq_lut": g.ganq_codebook,
                              "quant_time": time.time() - t0, "avg_loss": avg_loss,
@@ -93,5 +95,6 @@ class GPTQProcessor:
         the nn.Linear modules."""
         from ..nn_modules.backend import BACKEND, pack_model
 
-        pack_model(model, quant_result=self._results, qcfg=self.qcfg, backend=backend or BACKEND.AUTO)
+        packable = {k: v for k, v in self._results.items() if v.get("packable", True)}
+        pack_model(model, quant_result=packable, qcfg=self.qcfg, backend=backend or BACKEND.AUTO)
         return model

@@ -17,6 +17,8 @@ class NamedModule(torch.nn.Module):
             in_features, out_features = module.in_features, module.out_features
         elif type(module).__name__ == "Conv1D":  # transformers.pytorch_utils.Conv1D
             in_features, out_features = module.weight.shape[0], module.weight.shape[1]
+        elif isinstance(module, nn.Conv2d):  # named_module.py:44-46 of the reference
+            in_features, out_features = module.in_channels, module.out_channels
         else:
             raise NotImplementedError(f"Unsupported module.module type: `{type(module)}`")
         self.state.update({"in_features": in_features, "out_features": out_features})

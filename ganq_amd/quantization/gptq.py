@@ -63,8 +63,8 @@ class GPTQ:
         else:
             name = HF_OPTIMUM
             self.module = module
-        if not isinstance(self.module, nn.Linear) and not _is_conv1d(self.module):
-            raise NotImplementedError(f"GANQ HIP path supports nn.Linear / Conv1D modules, got {type(self.module)}")
+        if not isinstance(self.module, (nn.Linear, nn.Conv2d)) and not _is_conv1d(self.module):
+            raise NotImplementedError(f"GANQ HIP path supports nn.Linear / Conv1D / nn.Conv2d modules, got {type(self.module)}")
         self.qcfg = qcfg if qcfg else QuantizeConfig()
         self.device = self.module.weight.device
         if self.device.type != "cuda":
@@ -96,6 +96,8 @@ class GPTQ:
 
     def _clone_module(self):
         clone = self.module.weight.data.clone()
+        if isinstance(self.module, nn.Conv2d):
+            clone = clone.flatten(1)  # gptq.py:80-81: [out_channels, in_channels * kh * kw]
         if _is_conv1d(self.module):
             clone = clone.t()
         return clone.float().contiguous()
@@ -113,6 +115,12 @@ class GPTQ:
         if len(inp.shape) == 2:
             inp = inp.unsqueeze(0)
         batch = inp.shape[0]  # sequences, not tokens (gptq.py:104)
+        if isinstance(self.module, nn.Conv2d):
+            # gptq.py:111-121: the patches every output position sees (nn.Unfold), one "token" per (image, position):
+            # [B, C kh kw, L] -> [B L, C kh kw] in the layout the Hessian kernel streams (torch: tensor plumbing)
+            inp = torch.nn.functional.unfold(inp, self.module.kernel_size, dilation=self.module.dilation,
+                                             padding=self.module.padding, stride=self.module.stride)
+            inp = inp.permute(0, 2, 1).reshape(-1, inp.shape[1]).contiguous()
         if len(inp.shape) == 3:
             inp = inp.reshape((-1, inp.shape[-1]))
         if not hasattr(self, "H"):

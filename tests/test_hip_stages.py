@@ -233,6 +233,49 @@ def test_solve_s_helper_workgroups_on_concurrent_streams(hip, lib_options):
     assert t_muted < t_seq / 3 * 2.0 + 5e-3, "a tile whose helper never answers must lose about one DUO_TIMEOUT, not more"
 
 
+def test_solve_s_helper_workgroups_beside_another_process(hip):
+    """A second PROCESS keeps every CU busy with large matrix products while helped S-solve launches run: the helper of a tile may
+    then not be resident for a long time.  The indices must be those of the quiet run, and no launch may take anywhere near the
+    old 9 ms (20 M shader cycles) per abandoned helper wait, let alone hang: the tile-side wait is 0.5 ms since round 4."""
+    import subprocess
+    import sys
+    import time
+
+    W, H, L, T0 = synth(1024, 2048, 16, 51, corr=0.1)   # 64 tiles: two helpers per tile when the chip is free
+    d = (dev(W), dev(L), dev(T0))
+    ref = hip.solve_s(*d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        hip.solve_s(*d)
+    torch.cuda.synchronize()
+    quiet = (time.perf_counter() - t0) / 5
+    busy = ("import torch, time, sys\n"
+            "a = torch.randn(8192, 8192, device='cuda', dtype=torch.float16)\n"
+            "torch.cuda.synchronize(); print('busy', flush=True)\n"
+            "t0 = time.time()\n"
+            "while time.time() - t0 < 8.0:\n"
+            "    for _ in range(20): b = a @ a\n"
+            "    torch.cuda.synchronize()\n")
+    proc = subprocess.Popen([sys.executable, "-c", busy], stdout=subprocess.PIPE, text=True)
+    try:
+        assert proc.stdout.readline().strip() == "busy"
+        time.sleep(0.2)
+        worst = 0.0
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Q = hip.solve_s(*d)
+            torch.cuda.synchronize()
+            worst = max(worst, time.perf_counter() - t0)
+            assert torch.equal(Q, ref)
+    finally:
+        proc.kill()
+        proc.wait()
+    print(f"solve_s 1024 x 2048 with helpers: {quiet * 1e3:.2f} ms alone, worst of 10 beside a process saturating the GPU {worst * 1e3:.2f} ms")
+    assert worst < 0.25, "a helped launch beside another process took longer than 0.25 s"
+
+
 def test_solve_s_strided_L_and_empty(hip, oracle):
     W, H, L, T0 = synth(16, 96, 16, 10)
     Lbig = torch.zeros(96, 160, device="cuda")
