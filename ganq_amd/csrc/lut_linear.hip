@@ -729,14 +729,16 @@ size_t lut_gemm_workspace_bytes(int64_t M, int64_t m, int64_t n);
 // Prefill with many rows: dequantise the layer ONCE into the workspace and run the dense GEMM (gemm_h16.hip) -- every 256-row
 // tile of the fused kernel re-decodes the same weights.  Measured (MI355X, 4-bit fp16, round 4): 4096 x 4096 M = 4096 fused
 // 166 us, dense 116 + dequant; M = 2048 a tie; below, the dense tiles no longer fill the chip and the fused kernel's split of
-// in_features wins.  From >= 1024 rows on, when 256-row tiles give (nearly) every CU one or 128-row tiles do.
+// in_features wins.  From >= 1024 rows on, when 256-row tiles give (nearly) every CU one.
 static bool lut_dense_path(int64_t M, int64_t m, int64_t n) {
     const long long thr = opt_get(OPT_LUT_DENSE_M);
     if (thr == 0 || !gemm_h16_supported(M, m, n) || (n & 31) != 0) return false;
     if (thr > 0) return M >= thr;
     const int ncu = std::max(1, current_device_cus());
-    const int64_t t256 = ((M + 255) / 256) * ((m + 255) / 256), t128 = ((M + 127) / 128) * ((m + 255) / 256);
-    return M >= 1024 && (8 * t256 >= 7 * ncu || t128 >= ncu);  // 256-row tiles (nearly) fill the chip, or 128-row tiles do
+    const int64_t t256 = ((M + 255) / 256) * ((m + 255) / 256);
+    // 256-row tiles (nearly) fill the chip.  (Where only 128-row tiles would -- 4096 x 4096 at M = 2048 -- the dense path measures
+    // 90-104 us against 87-95 for the fused kernel: a tie, without the 32 MB round trip of the dequantised weight.)
+    return M >= 1024 && 8 * t256 >= 7 * ncu;
 }
 
 }  // namespace ganq
