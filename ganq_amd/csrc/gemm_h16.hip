@@ -50,6 +50,25 @@ __device__ __forceinline__ hg_f32x4 hg_mfma(hg_u32x4 a, hg_u32x4 b, hg_f32x4 c) 
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hg_f16x8, a), __builtin_bit_cast(hg_f16x8, b), c, 0, 0, 0);
 }
 
+// The same instruction with its accumulator PINNED to the accumulation registers ("+a"): with 256 of them per wave (four-wave kernel) hipcc
+// otherwise shuttles accumulator tiles between the two register files inside the K loop (1477 v_accvgpr moves and 242 spills in the
+// first build).  An asm statement is not reordered against other volatile asm, so the interleave below is the one written.
+template <bool BF16>
+__device__ __forceinline__ void hg_mfma_acc(hg_f32x4& acc, const hg_u32x4& a, const hg_u32x4& b) {
+    if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// acc = 0, born in an accumulation register: a matrix instruction with the inline constant 0 as C and zero operands (a vector-register
+// zero copied in would make the loop's phi a vector register again)
+template <bool BF16>
+__device__ __forceinline__ void hg_mfma_zero(hg_f32x4& acc, const hg_u32x4& z) {
+    // (s_nop: the zero operand was written by a vector move right in front, and hipcc's hazard recogniser does not see a matrix
+    // instruction in an asm statement -- without the wait the first tile starts from the register's previous contents)
+    if constexpr (BF16) asm volatile("s_nop 4\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));
+    else asm volatile("s_nop 4\n\tv_mfma_f32_16x16x32_f16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));
+}
+
 template <bool BF16, int BM>
 __global__ __launch_bounds__(HTHREADS, 1) void gemm_h16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                               const uint16_t* __restrict__ bias, const float* __restrict__ addend,
@@ -279,6 +298,209 @@ __global__ __launch_bounds__(HTHREADS, 1) void gemm_h16_kernel(const uint16_t* _
     }
 }
 
+// ---- 256 x 256 tile on FOUR waves: one wave per SIMD, wave tile 128 x 128 (64 accumulator tiles in the 256 accumulation registers a
+// lone wave has).  The 8-wave kernel above is bound by the LDS: 192 KB of fragment reads + 64 KB of LDS-DMA per K tile are 2048 LDS
+// cycles against 2048 matrix cycles, and its R epochs measure ~470 cycles against 256 of matrix work (matrix pipe busy 54 %).  A
+// 128 x 128 wave tile reads (8 + 8) x 2 fragments per K tile instead of 4 x (8 + 4) x 2 per wave pair: 128 + 64 = 192 KB -> 1536
+// cycles, and there is ONE barrier per K tile instead of eight.  With one wave per SIMD nothing else covers a wave's waits, so the
+// wave software-pipelines itself: the fragments of k half 1 are read while the 64 matrix instructions of k half 0 issue (a matrix
+// instruction occupies the pipe for 16 cycles; the wave issues LDS reads in between), the next K tile's first fragments during the
+// last 32 matrix instructions of this one.  LDS-DMA of tile t + 1 is issued at the top of tile t and waited for (vmcnt(0), barrier)
+// in the middle of tile t's second half: one whole K tile of flight.
+#ifdef HG_PROBE
+// developer build only (-DHG_PROBE, tools/dev/gemm_probe.sh): cycle counts of the four waves of workgroup 0, summed over the K tiles
+__device__ unsigned long long hg_probe_buf[4 * 8];
+#define HG_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define HG_T(v)
+#endif
+template <bool BF16>
+__global__ __launch_bounds__(256, 1) void gemm_h16_w4_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ bias, const float* __restrict__ addend,
+                                                            int M, int N, int K, int tiles_m, int tiles_n, uint16_t* __restrict__ y) {
+    constexpr int BM = 256;
+    constexpr int A_BYTES = BM * HBK * 2, B_BYTES = HBN * HBK * 2, BUF = A_BYTES + B_BYTES;
+    extern __shared__ __align__(1024) char hg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int nwg = tiles_m * tiles_n;
+    int bid = (int)blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int row0 = tm * BM, f0 = tn * HBN;
+    const int nt = K / HBK;
+
+    // LDS-DMA: a tile = 32 chunks of 8 rows x 128 B; wave wv takes chunks 8 wv .. 8 wv + 7 of both operands
+    uint32_t aoff[8], boff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = (wv * 8 + i) * 8 + (lane >> 3);
+        const int g = (lane & 7) ^ ((rl >> 1) & 7);
+        aoff[i] = (uint32_t)(((size_t)min(row0 + rl, M - 1) * K + g * 8) * 2);
+        boff[i] = (uint32_t)(((size_t)min(f0 + rl, N - 1) * K + g * 8) * 2);
+    }
+    const char* const xb = reinterpret_cast<const char*>(x);
+    const char* const wb = reinterpret_cast<const char*>(w);
+    // one LDS-DMA instruction: chunk i of the x tile (op 0) or the weight tile (op 1) of K tile t into buffer buf.  `sa` / `sb` are the
+    // tile's scalar base pointers, made opaque per K tile (else hipcc hoists base + lane offset out of the loop as 64-bit vector
+    // pointers and spends two 64-bit vector adds per instruction instead of using the instruction's scalar-base form)
+    auto stage_one = [&](const char* sbase, int op, int i, int buf) {
+        char* dst = hg_smem + buf * BUF + op * A_BYTES + (wv * 8 + i) * 1024;
+        __builtin_amdgcn_global_load_lds((hg_gptr)(sbase + (op ? boff[i] : aoff[i])), (hg_lptr)dst, 16, 0, 0);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)hg_smem;
+    const uint32_t fr_off = (uint32_t)((lane & 15) * 128 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 4));
+    const uint32_t a_base = lds0 + (uint32_t)(wr * 128 * 128) + fr_off;
+    const uint32_t b_base = lds0 + (uint32_t)A_BYTES + (uint32_t)(wc * 128 * 128) + fr_off;
+    auto lds_read = [&](uint32_t addr) -> hg_u32x4 {
+        typedef const hg_u32x4 __attribute__((address_space(3))) * lp;
+        return *reinterpret_cast<lp>(addr);
+    };
+
+    hg_f32x4 acc[8][8];
+    {
+        const hg_u32x4 z = hg_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hg_mfma_zero<BF16>(acc[i][j], z);
+    }
+    hg_u32x4 fa0[8], fb0[8], fa1[8], fb1[8];  // fragments of k half 0 / 1: rows tile i, features tile j
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        stage_one(xb, 0, i, 0);
+        stage_one(wb, 1, i, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        fa0[i] = lds_read(a_base + i * 2048);
+        fb0[i] = lds_read(b_base + i * 2048);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+#ifdef HG_PROBE
+    uint32_t pr[7] = {0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pstart = __builtin_readcyclecounter();
+#endif
+    auto ktile = [&](auto par_tag, const int t) {
+        constexpr int PAR = decltype(par_tag)::value;
+        // No branch in the stream: the last K tile prefetches ITSELF into the other buffer (nobody reads it), one tile of extra
+        // traffic per workgroup instead of a scalar branch around every LDS-DMA instruction.
+        constexpr bool more = true;
+        const int tn = t + 1 < nt ? t + 1 : nt - 1;
+        const uint32_t ab = a_base + (uint32_t)(PAR * BUF), bb = b_base + (uint32_t)(PAR * BUF);
+        const uint32_t an = a_base + (uint32_t)((PAR ^ 1) * BUF), bn = b_base + (uint32_t)((PAR ^ 1) * BUF);
+        const char* sa = xb + (size_t)tn * (HBK * 2);
+        const char* sb = wb + (size_t)tn * (HBK * 2);
+        asm volatile("" : "+s"(sa), "+s"(sb));
+        HG_T(p0);
+        // ---- k half 0: 64 matrix instructions; behind every fourth one of the 16 fragment reads of k half 1 AND one of the 16 LDS-DMA
+        // instructions of K tile t + 1 (its buffer is free: every wave passed the previous tile's barrier after its last read of it)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hg_mfma_acc<BF16>(acc[i][j], fb0[j], fa0[i]);
+                if (j == 3) {
+                    fa1[i] = lds_read((ab + i * 2048) ^ 64u);
+                    if (more) stage_one(sa, 0, i, PAR ^ 1);
+                }
+                if (j == 7) {
+                    fb1[i] = lds_read((bb + i * 2048) ^ 64u);
+                    if (more) stage_one(sb, 1, i, PAR ^ 1);
+                }
+            }
+        }
+        HG_T(p1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HG_T(p2);
+        // ---- k half 1, first 32 matrix instructions
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hg_mfma_acc<BF16>(acc[i][j], fb1[j], fa1[i]);
+        HG_T(p3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t + 1 has had a whole K tile to land; one barrier per K tile
+        HG_T(p4);
+        __builtin_amdgcn_s_barrier();
+        HG_T(p5);
+        // ---- k half 1, last 32 matrix instructions; the next tile's first fragments go out behind every second
+#pragma unroll
+        for (int i = 4; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hg_mfma_acc<BF16>(acc[i][j], fb1[j], fa1[i]);
+                if (more && (j & 1)) {  // (compile-time)
+                    const int r = (i - 4) * 4 + (j >> 1);  // 0 .. 15
+                    if (r < 8) fa0[r] = lds_read(an + r * 2048);
+                    else fb0[r - 8] = lds_read(bn + (r - 8) * 2048);
+                }
+            }
+        }
+        HG_T(p6);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef HG_PROBE
+        HG_T(p7);
+        pr[0] += (uint32_t)(p1 - p0); pr[1] += (uint32_t)(p2 - p1); pr[2] += (uint32_t)(p3 - p2); pr[3] += (uint32_t)(p4 - p3);
+        pr[4] += (uint32_t)(p5 - p4); pr[5] += (uint32_t)(p6 - p5); pr[6] += (uint32_t)(p7 - p6);
+#endif
+    };
+    for (int t = 0; t < nt; t += 2) {
+        ktile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nt) ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    // the matrix instructions are asm statements: hipcc's hazard recogniser does not know that the accumulation registers it is
+    // about to read were written by the matrix pipe
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef HG_PROBE
+    if (bid == 0 && lane == 0) {
+        for (int k = 0; k < 7; ++k) hg_probe_buf[wv * 8 + k] = pr[k];
+        hg_probe_buf[wv * 8 + 7] = __builtin_readcyclecounter() - pstart;
+    }
+#endif
+
+    // ---- epilogue: acc[i][j][r] = y[row0 + 128 wr + 16 i + (l & 15)][f0 + 128 wc + 16 j + 4 (l >> 4) + r]
+    const int fq = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = f0 + wc * 128 + j * 16 + fq;
+        if (f >= N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                bv[r] = BF16 ? __builtin_bit_cast(float, (uint32_t)bias[f + r] << 16) : (float)__builtin_bit_cast(_Float16, bias[f + r]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + wr * 128 + i * 16 + (lane & 15);
+            if (row >= M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[r];
+            if (addend) {
+                const hg_f32x4 ad = *reinterpret_cast<const hg_f32x4*>(addend + (int64_t)row * N + f);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += ad[r];
+            }
+            uint16_t o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[r] = BF16 ? __builtin_bit_cast(uint16_t, (__bf16)v[r]) : __builtin_bit_cast(uint16_t, (_Float16)v[r]);
+            uint2 pk;
+            pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+            pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+            *reinterpret_cast<uint2*>(y + (int64_t)row * N + f) = pk;
+        }
+    }
+}
+
 }  // namespace
 
 // shapes the kernel serves: whole K tiles of 64, features in quads, 16-byte aligned rows (all of them true for every layer whose
@@ -296,6 +518,25 @@ int gemm_h16(const void* x, const void* w, const void* bias, const float* addend
     const int64_t t256 = ((M + 255) / 256) * tiles_n;
     const long long force = opt_get(OPT_GEMM_H16_BM);
     const bool big = force > 0 ? force >= 256 : t256 >= ncu;
+    if (force == 512) {  // developer: the four-wave kernel (128 x 128 wave tiles)
+        const int tiles_m = (int)((M + 255) / 256);
+        const size_t lds = hg_lds_bytes<256>();
+        if (dtype == 1) {
+            int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_h16_w4_kernel<true>), lds);
+            if (rc_) return rc_;
+            hipLaunchKernelGGL((gemm_h16_w4_kernel<true>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds, stream,
+                               static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w), static_cast<const uint16_t*>(bias), addend, (int)M, (int)N, (int)K,
+                               tiles_m, tiles_n, static_cast<uint16_t*>(y));
+        } else {
+            int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_h16_w4_kernel<false>), lds);
+            if (rc_) return rc_;
+            hipLaunchKernelGGL((gemm_h16_w4_kernel<false>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds, stream,
+                               static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w), static_cast<const uint16_t*>(bias), addend, (int)M, (int)N, (int)K,
+                               tiles_m, tiles_n, static_cast<uint16_t*>(y));
+        }
+        GANQ_LAUNCH_CHECK();
+        return 0;
+    }
     const uint16_t* xp = static_cast<const uint16_t*>(x);
     const uint16_t* wp = static_cast<const uint16_t*>(w);
     const uint16_t* bp = static_cast<const uint16_t*>(bias);
@@ -330,3 +571,9 @@ extern "C" int ganq_debug_gemm_h16(const void* x, const void* w, const void* bia
     if (!x || !w || !y) return fail(-3, "ganq_debug_gemm_h16: null pointer");
     return gemm_h16(x, w, bias, addend, dtype, M, N, K, y, static_cast<hipStream_t>(stream));
 }
+
+#ifdef HG_PROBE
+extern "C" int ganq_debug_gemm_probe(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hg_probe_buf), sizeof(unsigned long long) * 32);
+}
+#endif

@@ -13,7 +13,7 @@ for (M, N, K) in shapes:
     w = (0.05 * torch.randn(N, K, device="cuda", generator=g)).half()
     want = (x.float() @ w.float().T)
     scale = float(want.abs().max())
-    for bm in (0, 128, 256):
+    for bm in (0, 128, 256, 512):
         _lib.debug_option("GANQ_GEMM_H16_BM", bm if bm else None)
         worst = 0.0
         for rep in range(8):
