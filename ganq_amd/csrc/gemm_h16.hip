@@ -50,6 +50,20 @@ __device__ __forceinline__ hg_f32x4 hg_mfma(hg_u32x4 a, hg_u32x4 b, hg_f32x4 c) 
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hg_f16x8, a), __builtin_bit_cast(hg_f16x8, b), c, 0, 0, 0);
 }
 
+// Tile of workgroup number `bid` (after the per-L2 renumbering: the 32 CUs behind one L2 hold consecutive numbers): panels of HG_PANEL
+// rows of tiles, walked column by column, so that the workgroups resident behind one L2 cover a 4 x 8 block of tiles (12 operand
+// panels fetched for 32 tiles) instead of a 1 x 32 or 2 x 16 strip (33 or 18): less traffic past the L2, which on this part is
+// power as much as time -- the dense kernels run against the power limit, not the issue rate (tools/dev/mfma_peak.hip).
+// (128-row tiles: 8 x 4 blocks -- the block whose operand panels are smallest, rows x BM + columns x 256)
+template <int HG_PANEL>
+__device__ __forceinline__ void hg_tile_of(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int per_panel = HG_PANEL * tiles_n;
+    const int p = bid / per_panel, idx = bid - p * per_panel;
+    const int ph = min(HG_PANEL, tiles_m - p * HG_PANEL);  // rows of tiles in this panel (the last one may be short)
+    tn = idx / ph;
+    tm = p * HG_PANEL + (idx - tn * ph);
+}
+
 // The same instruction with its accumulator PINNED to the accumulation registers ("+a"): with 256 of them per wave (four-wave kernel) hipcc
 // otherwise shuttles accumulator tiles between the two register files inside the K loop (1477 v_accvgpr moves and 242 spills in the
 // first build).  An asm statement is not reordered against other volatile asm, so the interleave below is the one written.
@@ -91,7 +105,8 @@ __global__ __launch_bounds__(HTHREADS, 1) void gemm_h16_kernel(const uint16_t* _
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective also when nwg % 8 != 0
     }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    hg_tile_of<(BM == 128 ? 8 : 4)>(bid, tiles_m, tiles_n, tm, tn);
     const int row0 = tm * BM, f0 = tn * HBN;
     const int nt = K / HBK;
 
@@ -299,16 +314,20 @@ __global__ __launch_bounds__(HTHREADS, 1) void gemm_h16_kernel(const uint16_t* _
 }
 
 // ---- 256 x 256 tile on FOUR waves: one wave per SIMD, wave tile 128 x 128 (64 accumulator tiles in the 256 accumulation registers a
-// lone wave has).  The 8-wave kernel above is bound by the LDS: 192 KB of fragment reads + 64 KB of LDS-DMA per K tile are 2048 LDS
-// cycles against 2048 matrix cycles, and its R epochs measure ~470 cycles against 256 of matrix work (matrix pipe busy 54 %).  A
-// 128 x 128 wave tile reads (8 + 8) x 2 fragments per K tile instead of 4 x (8 + 4) x 2 per wave pair: 128 + 64 = 192 KB -> 1536
-// cycles, and there is ONE barrier per K tile instead of eight.  With one wave per SIMD nothing else covers a wave's waits, so the
-// wave software-pipelines itself: the fragments of k half 1 are read while the 64 matrix instructions of k half 0 issue (a matrix
-// instruction occupies the pipe for 16 cycles; the wave issues LDS reads in between), the next K tile's first fragments during the
-// last 32 matrix instructions of this one.  LDS-DMA of tile t + 1 is issued at the top of tile t and waited for (vmcnt(0), barrier)
-// in the middle of tile t's second half: one whole K tile of flight.
+// lone wave has).  Fragment traffic per matrix instruction is a third less than with 8 waves (8 + 8 fragments feed 64 instructions
+// instead of 8 + 4 feeding 32), and nothing is shared between waves but the LDS tiles.  What a lone wave cannot do is hide a wait
+// behind another wave, so every wait is engineered away (measured with the cycle probes below, -DHG_PROBE):
+//   * K is cut into SLICES of 32 (one matrix instruction deep), FOUR LDS stages of 32 KB.  During slice s a wave issues its 64 matrix
+//     instructions from registers, reads the 16 fragments of slice s + 1 from stage (s + 1) % 4 (one ds_read behind every third
+//     instruction) and sends its share of slice s + 4 into stage s % 4 -- free since the barrier that opened slice s -- by LDS-DMA (one
+//     instruction behind every eighth: the texture path takes ~16 cycles per 1 KB instruction and four waves share it; issued
+//     back-to-back they stalled the matrix stream by ~26 cycles each in the first version).  LDS-DMA has two to three slices
+//     (2200 - 3300 cycles) to land; the first version (two 64-wide stages, one slice of flight) waited 170 cycles per tile for it.
+//   * one barrier per slice, preceded by s_waitcnt vmcnt(16): the LDS-DMA of slice s + 1 has landed, those of s + 2, s + 3 fly on.
+//   * rows are 64 B in LDS; the 16-byte slot is XORed with (row >> 2) & 3: the 16 lanes of a quarter wave read 16 different
+//     16-byte bank groups (LDS-DMA writes lane-linear, so the permutation is applied to the global source slot).
 #ifdef HG_PROBE
-// developer build only (-DHG_PROBE, tools/dev/gemm_probe.sh): cycle counts of the four waves of workgroup 0, summed over the K tiles
+// developer build only (-DHG_PROBE, tools/dev/gemm_probe.sh): cycle counts of the four waves of workgroup 0, summed over the slices
 __device__ unsigned long long hg_probe_buf[4 * 8];
 #define HG_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #else
@@ -318,10 +337,11 @@ template <bool BF16>
 __global__ __launch_bounds__(256, 1) void gemm_h16_w4_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                             const uint16_t* __restrict__ bias, const float* __restrict__ addend,
                                                             int M, int N, int K, int tiles_m, int tiles_n, uint16_t* __restrict__ y) {
-    constexpr int BM = 256;
-    constexpr int A_BYTES = BM * HBK * 2, B_BYTES = HBN * HBK * 2, BUF = A_BYTES + B_BYTES;
+    constexpr int BM = 256, SK = 32;
+    constexpr int A_ST = BM * SK * 2, B_ST = HBN * SK * 2, ST = A_ST + B_ST;  // 16 KB + 16 KB per stage
     extern __shared__ __align__(1024) char hg_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the LDS-DMA destinations below are scalar arithmetic)
     const int wr = wv >> 1, wc = wv & 1;
     const int nwg = tiles_m * tiles_n;
     int bid = (int)blockIdx.x;
@@ -329,32 +349,33 @@ __global__ __launch_bounds__(256, 1) void gemm_h16_w4_kernel(const uint16_t* __r
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    hg_tile_of<4>(bid, tiles_m, tiles_n, tm, tn);
     const int row0 = tm * BM, f0 = tn * HBN;
-    const int nt = K / HBK;
+    const int ns = K / SK;  // (even: K is a multiple of 64)
 
-    // LDS-DMA: a tile = 32 chunks of 8 rows x 128 B; wave wv takes chunks 8 wv .. 8 wv + 7 of both operands
-    uint32_t aoff[8], boff[8];
+    // LDS-DMA: one instruction = 16 rows x 64 B; a stage = 16 + 16 chunks, wave wv takes chunks 4 wv .. 4 wv + 3 of both operands
+    uint32_t aoff[4], boff[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int rl = (wv * 8 + i) * 8 + (lane >> 3);
-        const int g = (lane & 7) ^ ((rl >> 1) & 7);
+    for (int i = 0; i < 4; ++i) {
+        const int rl = (wv * 4 + i) * 16 + (lane >> 2);
+        const int g = (lane & 3) ^ ((rl >> 2) & 3);
         aoff[i] = (uint32_t)(((size_t)min(row0 + rl, M - 1) * K + g * 8) * 2);
         boff[i] = (uint32_t)(((size_t)min(f0 + rl, N - 1) * K + g * 8) * 2);
     }
     const char* const xb = reinterpret_cast<const char*>(x);
     const char* const wb = reinterpret_cast<const char*>(w);
-    // one LDS-DMA instruction: chunk i of the x tile (op 0) or the weight tile (op 1) of K tile t into buffer buf.  `sa` / `sb` are the
-    // tile's scalar base pointers, made opaque per K tile (else hipcc hoists base + lane offset out of the loop as 64-bit vector
-    // pointers and spends two 64-bit vector adds per instruction instead of using the instruction's scalar-base form)
-    auto stage_one = [&](const char* sbase, int op, int i, int buf) {
-        char* dst = hg_smem + buf * BUF + op * A_BYTES + (wv * 8 + i) * 1024;
-        __builtin_amdgcn_global_load_lds((hg_gptr)(sbase + (op ? boff[i] : aoff[i])), (hg_lptr)dst, 16, 0, 0);
+    // instruction d (0 .. 7) of a slice: operand d & 1, chunk d >> 1 of this wave; `sa` / `sb` = the slice's scalar base pointers
+    auto dma_one = [&](const char* sa, const char* sb, int d, int buf) {
+        const int op = d & 1, ci = d >> 1;
+        char* dst = hg_smem + buf * ST + op * A_ST + (wv * 4 + ci) * 1024;
+        const char* src = op ? sb + boff[ci] : sa + aoff[ci];
+        __builtin_amdgcn_global_load_lds((hg_gptr)src, (hg_lptr)dst, 16, 0, 0);
     };
     const uint32_t lds0 = (uint32_t)(uintptr_t)hg_smem;
-    const uint32_t fr_off = (uint32_t)((lane & 15) * 128 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 4));
-    const uint32_t a_base = lds0 + (uint32_t)(wr * 128 * 128) + fr_off;
-    const uint32_t b_base = lds0 + (uint32_t)A_BYTES + (uint32_t)(wc * 128 * 128) + fr_off;
+    const uint32_t fr_off = (uint32_t)((lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) << 4));
+    const uint32_t a_base = lds0 + (uint32_t)(wr * 128 * 64) + fr_off;
+    const uint32_t b_base = lds0 + (uint32_t)A_ST + (uint32_t)(wc * 128 * 64) + fr_off;
     auto lds_read = [&](uint32_t addr) -> hg_u32x4 {
         typedef const hg_u32x4 __attribute__((address_space(3))) * lp;
         return *reinterpret_cast<lp>(addr);
@@ -368,100 +389,80 @@ __global__ __launch_bounds__(256, 1) void gemm_h16_w4_kernel(const uint16_t* __r
 #pragma unroll
             for (int j = 0; j < 8; ++j) hg_mfma_zero<BF16>(acc[i][j], z);
     }
-    hg_u32x4 fa0[8], fb0[8], fa1[8], fb1[8];  // fragments of k half 0 / 1: rows tile i, features tile j
+    hg_u32x4 fa[2][8], fb[2][8];  // fragments of slice parity 0 / 1: rows tile i, features tile j
 
+    // prologue: slices 0 .. 3 in flight (a slice past the end re-fetches the last one: nobody reads it, and the counted waits stay uniform)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        stage_one(xb, 0, i, 0);
-        stage_one(wb, 1, i, 0);
+    for (int b = 0; b < 4; ++b) {
+        const int sl = b < ns ? b : ns - 1;
+        const char* sa = xb + (size_t)sl * (SK * 2);
+        const char* sb = wb + (size_t)sl * (SK * 2);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dma_one(sa, sb, d, b);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        fa0[i] = lds_read(a_base + i * 2048);
-        fb0[i] = lds_read(b_base + i * 2048);
+        fa[0][i] = lds_read(a_base + i * 1024);
+        fb[0][i] = lds_read(b_base + i * 1024);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
 #ifdef HG_PROBE
-    uint32_t pr[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t pr[4] = {0, 0, 0, 0};
     const unsigned long long pstart = __builtin_readcyclecounter();
+    const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
 #endif
-    auto ktile = [&](auto par_tag, const int t) {
-        constexpr int PAR = decltype(par_tag)::value;
-        // No branch in the stream: the last K tile prefetches ITSELF into the other buffer (nobody reads it), one tile of extra
-        // traffic per workgroup instead of a scalar branch around every LDS-DMA instruction.
-        constexpr bool more = true;
-        const int tn = t + 1 < nt ? t + 1 : nt - 1;
-        const uint32_t ab = a_base + (uint32_t)(PAR * BUF), bb = b_base + (uint32_t)(PAR * BUF);
-        const uint32_t an = a_base + (uint32_t)((PAR ^ 1) * BUF), bn = b_base + (uint32_t)((PAR ^ 1) * BUF);
-        const char* sa = xb + (size_t)tn * (HBK * 2);
-        const char* sb = wb + (size_t)tn * (HBK * 2);
-        asm volatile("" : "+s"(sa), "+s"(sb));
+    auto slice = [&](auto b_tag, const int s) {
+        constexpr int B = decltype(b_tag)::value, P = B & 1, BN = (B + 1) & 3;
         HG_T(p0);
-        // ---- k half 0: 64 matrix instructions; behind every fourth one of the 16 fragment reads of k half 1 AND one of the 16 LDS-DMA
-        // instructions of K tile t + 1 (its buffer is free: every wave passed the previous tile's barrier after its last read of it)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // slice s + 1 has landed (mine); behind the barrier: everybody's
+        HG_T(p1);
+        __builtin_amdgcn_s_barrier();  // ... and every wave has read its fragments of slice s: stage B is free
+        HG_T(p2);
+        const int sl = s + 4 < ns ? s + 4 : ns - 1;
+        const char* sa = xb + (size_t)sl * (SK * 2);
+        const char* sb = wb + (size_t)sl * (SK * 2);
+        asm volatile("" : "+s"(sa), "+s"(sb));
+        const uint32_t an = a_base + (uint32_t)(BN * ST), bn = b_base + (uint32_t)(BN * ST);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                hg_mfma_acc<BF16>(acc[i][j], fb0[j], fa0[i]);
-                if (j == 3) {
-                    fa1[i] = lds_read((ab + i * 2048) ^ 64u);
-                    if (more) stage_one(sa, 0, i, PAR ^ 1);
+                const int n = i * 8 + j;
+                hg_mfma_acc<BF16>(acc[i][j], fb[P][j], fa[P][i]);
+                if (n % 3 == 1 && n / 3 < 16) {  // fragments of slice s + 1, in the order the next slice uses them
+                    const int r = n / 3;
+                    if (r == 0) fa[P ^ 1][0] = lds_read(an);
+                    else if (r <= 8) fb[P ^ 1][r - 1] = lds_read(bn + (r - 1) * 1024);
+                    else fa[P ^ 1][r - 8] = lds_read(an + (r - 8) * 1024);
                 }
-                if (j == 7) {
-                    fb1[i] = lds_read((bb + i * 2048) ^ 64u);
-                    if (more) stage_one(sb, 1, i, PAR ^ 1);
-                }
+                if (n % 8 == 5) dma_one(sa, sb, n / 8, B);
             }
         }
-        HG_T(p1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        HG_T(p2);
-        // ---- k half 1, first 32 matrix instructions
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hg_mfma_acc<BF16>(acc[i][j], fb1[j], fa1[i]);
         HG_T(p3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t + 1 has had a whole K tile to land; one barrier per K tile
-        HG_T(p4);
-        __builtin_amdgcn_s_barrier();
-        HG_T(p5);
-        // ---- k half 1, last 32 matrix instructions; the next tile's first fragments go out behind every second
-#pragma unroll
-        for (int i = 4; i < 8; ++i) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                hg_mfma_acc<BF16>(acc[i][j], fb1[j], fa1[i]);
-                if (more && (j & 1)) {  // (compile-time)
-                    const int r = (i - 4) * 4 + (j >> 1);  // 0 .. 15
-                    if (r < 8) fa0[r] = lds_read(an + r * 2048);
-                    else fb0[r - 8] = lds_read(bn + (r - 8) * 2048);
-                }
-            }
-        }
-        HG_T(p6);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef HG_PROBE
-        HG_T(p7);
+        HG_T(p4);
         pr[0] += (uint32_t)(p1 - p0); pr[1] += (uint32_t)(p2 - p1); pr[2] += (uint32_t)(p3 - p2); pr[3] += (uint32_t)(p4 - p3);
-        pr[4] += (uint32_t)(p5 - p4); pr[5] += (uint32_t)(p6 - p5); pr[6] += (uint32_t)(p7 - p6);
 #endif
     };
-    for (int t = 0; t < nt; t += 2) {
-        ktile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < nt) ktile(std::integral_constant<int, 1>{}, t + 1);
+    for (int s = 0; s < ns; s += 4) {
+        slice(std::integral_constant<int, 0>{}, s);
+        slice(std::integral_constant<int, 1>{}, s + 1);
+        if (s + 2 >= ns) break;
+        slice(std::integral_constant<int, 2>{}, s + 2);
+        slice(std::integral_constant<int, 3>{}, s + 3);
     }
     // the matrix instructions are asm statements: hipcc's hazard recogniser does not know that the accumulation registers it is
-    // about to read were written by the matrix pipe
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // about to read were written by the matrix pipe; and no LDS-DMA may be in flight when the workgroup's LDS is handed on
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
 #ifdef HG_PROBE
     if (bid == 0 && lane == 0) {
-        for (int k = 0; k < 7; ++k) hg_probe_buf[wv * 8 + k] = pr[k];
+        for (int k = 0; k < 4; ++k) hg_probe_buf[wv * 8 + k] = pr[k];
         hg_probe_buf[wv * 8 + 7] = __builtin_readcyclecounter() - pstart;
+        hg_probe_buf[wv * 8 + 4] = __builtin_amdgcn_s_memrealtime() - rstart;
     }
 #endif
 
@@ -499,6 +500,10 @@ __global__ __launch_bounds__(256, 1) void gemm_h16_w4_kernel(const uint16_t* __r
             *reinterpret_cast<uint2*>(y + (int64_t)row * N + f) = pk;
         }
     }
+#ifdef HG_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (bid == 0 && lane == 0) hg_probe_buf[wv * 8 + 5] = __builtin_amdgcn_s_memrealtime() - rstart;
+#endif
 }
 
 }  // namespace
@@ -509,7 +514,7 @@ bool gemm_h16_supported(int64_t M, int64_t N, int64_t K) {
     return M >= 1 && N >= 4 && (N & 3) == 0 && K >= 64 && (K & 63) == 0 && M * K * 2 < (1ll << 32) && N * K * 2 < (1ll << 32) && M < (1 << 30);
 }
 
-// BM: 256-row tiles when they fill the chip at least once, else 128-row tiles (twice the workgroups)
+// BM: 256-row tiles when they fill at least 7/8 of the chip once, else 128-row tiles (twice the workgroups)
 int gemm_h16(const void* x, const void* w, const void* bias, const float* addend, int dtype, int64_t M, int64_t N, int64_t K, void* y,
              hipStream_t stream) {
     if (!gemm_h16_supported(M, N, K)) return fail(-1, "gemm_h16: shape %lld x %lld x %lld not supported", (long long)M, (long long)N, (long long)K);
@@ -517,10 +522,10 @@ int gemm_h16(const void* x, const void* w, const void* bias, const float* addend
     const int tiles_n = (int)((N + HBN - 1) / HBN);
     const int64_t t256 = ((M + 255) / 256) * tiles_n;
     const long long force = opt_get(OPT_GEMM_H16_BM);
-    const bool big = force > 0 ? force >= 256 : t256 >= ncu;
+    const bool big = force > 0 ? force >= 256 : 8 * t256 >= 7 * ncu;  // (224 tiles of 256 rows on 256 CUs: 112 us against 139 us with 128-row tiles)
     if (force == 512) {  // developer: the four-wave kernel (128 x 128 wave tiles)
         const int tiles_m = (int)((M + 255) / 256);
-        const size_t lds = hg_lds_bytes<256>();
+        const size_t lds = 4 * (size_t)(256 + HBN) * 32 * 2;  // four stages of 32-wide slices
         if (dtype == 1) {
             int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_h16_w4_kernel<true>), lds);
             if (rc_) return rc_;

@@ -735,10 +735,11 @@ static bool lut_dense_path(int64_t M, int64_t m, int64_t n) {
     if (thr == 0 || !gemm_h16_supported(M, m, n) || (n & 31) != 0) return false;
     if (thr > 0) return M >= thr;
     const int ncu = std::max(1, current_device_cus());
-    const int64_t t256 = ((M + 255) / 256) * ((m + 255) / 256);
-    // 256-row tiles (nearly) fill the chip.  (Where only 128-row tiles would -- 4096 x 4096 at M = 2048 -- the dense path measures
-    // 90-104 us against 87-95 for the fused kernel: a tie, without the 32 MB round trip of the dequantised weight.)
-    return M >= 1024 && 8 * t256 >= 7 * ncu;
+    const int64_t t128 = ((M + 127) / 128) * ((m + 255) / 256);
+    // the dense kernel's smaller tile (128 x 256) fills the chip at least once.  (4096 x 4096 at M = 2048, 256 such tiles: 73 + 12 us
+    // against 94 for the fused kernel since the dense kernel walks its tiles in L2-sized blocks; at M = 1024, 128 tiles: 63 + 12
+    // against 72 the other way round.)
+    return M >= 1024 && t128 >= ncu;
 }
 
 }  // namespace ganq

@@ -12,10 +12,11 @@ torch.cuda.synchronize()
 h = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 32)()
 assert h.ganq_debug_gemm_probe(buf) == 0
-names = ["k half 0 (64 mfma + 16 reads + 16 dma)", "wait lds", "k half 1 a (32 mfma)", "wait dma", "barrier", "k half 1 b (32 mfma + 16 reads)", "wait lds"]
-nt = K // 64
+names = ["wait dma (vmcnt 16)", "barrier", "64 mfma + 16 reads + 8 dma", "wait lds"]
+nt = K // 32
 for wv in range(4):
     v = [int(buf[wv * 8 + k]) for k in range(8)]
-    print(f"wave {wv}: K loop {v[7]} cycles = {v[7] / nt:.0f} per K tile (128 matrix instructions = 2048 pipe cycles)")
-    for k in range(7):
-        print(f"    {names[k]:45s} {v[k] / nt:8.1f} cycles per K tile")
+    print(f"wave {wv}: K loop {v[7]} cycles = {v[7] / nt:.0f} per slice (64 matrix instructions = 1024 pipe cycles)")
+    print(f"    100 MHz clock: K loop {v[4] / 100:.1f} us ({v[7] / (v[4] * 10.0):.2f} GHz), K loop + epilogue {v[5] / 100:.1f} us")
+    for k in range(4):
+        print(f"    {names[k]:45s} {v[k] / nt:8.1f} cycles per slice")
