@@ -36,6 +36,10 @@ SIGNATURES = {
     "ganq_debug_gemm_h16": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp]),
     "ganq_hessian_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "ganq_hessian_t_supported": (ctypes.c_int, [_c_i64, _c_i64]),
+    "ganq_hessian_t_workspace_bytes": (_c_sz, [_c_i64]),
+    "ganq_hessian_stage_t": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
+    "ganq_hessian_accum_t": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
     "ganq_cholesky_workspace_bytes": (_c_sz, [_c_i64]),
     "ganq_cholesky": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_sz, _c_vp]),
     "ganq_prologue_rowstats": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp]),
@@ -431,6 +435,42 @@ def hessian_accum(H, X, nsamples_before: int, batch: int):
     ws = _workspace(nbytes, H.device) if nbytes else None
     _call("ganq_hessian_accum", (H, X, ws), H.data_ptr(), X.data_ptr(), code, rows, n, int(nsamples_before), int(batch),
           ws.data_ptr() if ws is not None else None, int(nbytes), _ST)
+    return H
+
+
+def hessian_t_supported(n: int, stage_tokens: int, device=None) -> bool:
+    """whether a layer of n in_features is served by the transposed staging path (staging buffer Xt [n, stage_tokens])"""
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        return bool(lib().ganq_hessian_t_supported(int(n), int(stage_tokens)))
+
+
+def hessian_stage_t(Xt, X, tok0: int):
+    """the transposing staging copy of one calibration batch: Xt[:, tok0 : tok0 + rows] = X^T  (X [rows, n], Xt [n, ldt], fp16 / bf16)"""
+    code = _act_dtype(X, "X")
+    if not (Xt.is_cuda and Xt.dtype == X.dtype and Xt.dim() == 2 and Xt.is_contiguous()) or _act_dtype(Xt, "Xt") != code:
+        raise GanqHipError("Xt must be a contiguous cuda tensor [in_features, tokens] of X's dtype")
+    X = X.contiguous()
+    rows, n = X.shape
+    if Xt.shape[0] != n or tok0 < 0 or tok0 + rows > Xt.shape[1]:
+        raise GanqHipError(f"hessian_stage_t: batch {tuple(X.shape)} at token {tok0} does not fit Xt{tuple(Xt.shape)}")
+    _call("ganq_hessian_stage_t", (Xt, X), Xt.data_ptr(), Xt.shape[1], X.data_ptr(), rows, n, int(tok0), _ST)
+    return Xt
+
+
+def hessian_accum_t(H, Xt, rows: int, nsamples_before: int, batch: int):
+    """gptq.py:96-131 for a staged group in transposed layout: H [n,n] fp32 (in place), Xt [n, ldt], its first `rows` tokens
+    (a multiple of 32) = `batch` sequences"""
+    if not (H.is_cuda and H.dtype == torch.float32 and H.is_contiguous()):
+        raise GanqHipError("H must be a contiguous float32 cuda tensor")
+    code = _act_dtype(Xt, "Xt")
+    if not (Xt.dim() == 2 and Xt.is_contiguous() and H.shape == (Xt.shape[0], Xt.shape[0])):
+        raise GanqHipError(f"shape mismatch H{tuple(H.shape)} Xt{tuple(Xt.shape)}")
+    n, ldt = Xt.shape
+    with torch.cuda.device(H.device):
+        nbytes = lib().ganq_hessian_t_workspace_bytes(n)
+    ws = _workspace(nbytes, H.device)
+    _call("ganq_hessian_accum_t", (H, Xt, ws), H.data_ptr(), Xt.data_ptr(), ldt, code, int(rows), n, int(nsamples_before), int(batch),
+          ws.data_ptr(), int(nbytes), _ST)
     return H
 
 

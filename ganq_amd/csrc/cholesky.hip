@@ -90,8 +90,8 @@ __device__ __forceinline__ void load_block(float (*dst)[CP], const float* __rest
 }
 
 // Diagonal 128x128 block as 4x4 blocks of 32.  Per block column kb: wave 0 factors the 32x32 diagonal block with one
-// row per lane in registers (pivot / column broadcasts are v_readlane, no LDS round trips) and inverts it the same
-// way (one column of the inverse per lane); the blocks below are multiplied by that inverse and the trailing blocks
+// row per lane in registers (pivot / column broadcasts are v_readlane, no LDS round trips) and inverts it in the same
+// instructions (one column of the inverse per lane of the upper half wave); the blocks below are multiplied by that inverse and the trailing blocks
 // updated on the matrix cores.  Only the four 32x32 inverses leave the kernel: the panel kernel solves block-wise.
 __global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, int64_t lda, int j, int nb,
                                                         float* __restrict__ Xout, int* __restrict__ info) {
@@ -99,49 +99,43 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, i
     float(*S)[CP] = reinterpret_cast<float(*)[CP]>(sm);  // the block, lower part
     float* Xd = sm + CB * CP;                              // [4][32][XP]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < CB * CB; i += 256) {
-        const int r = i / CB, c = i % CB;
-        S[r][c] = (r < nb && c <= r) ? A[(int64_t)(j + r) * lda + j + c] : (r == c ? 1.0f : 0.0f);
-    }
+    // (all 16 row segments of a thread in flight at once: the element-wise loop this replaces was 64 dependent round trips to
+    // L2 -- a third of the kernel's 64 us in round 3)
+    load_block(S, A, lda, j, nb, j, nb, tid, true);
+    __syncthreads();
+    if (tid >= nb && tid < CB) S[tid][tid] = 1.0f;  // a short last block is padded with the identity
     __syncthreads();
     for (int kb = 0; kb < 4; ++kb) {
         if (wv == 0) {
-            const int r = lane & 31;  // lanes 32..63 mirror 0..31 (their results are not stored)
-            float a[32], x[32];
+            // Lanes 0..31: row r of the block, factored right-looking.  Lanes 32..63: column r of the block's INVERSE, by the
+            // right-looking form of the forward substitution -- s[c2] -= L[c2][c] x[c] -- whose multipliers L[c2][c] are exactly
+            // the broadcasts the factor's own update a[c2] -= L[c2][c] L[r][c] needs: one v_readlane + one fma per (c, c2) serve
+            // both halves, and the inverse costs no instruction of its own (it was a second 496-broadcast chain behind the factor).
+            const int r = lane & 31;
+            const bool inv = lane >= 32;
+            float z[32];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) a[c] = S[32 * kb + r][32 * kb + c];
+            for (int c = 0; c < 32; ++c) z[c] = inv ? (r == c ? 1.0f : 0.0f) : S[32 * kb + r][32 * kb + c];
             int bad = 0;
-            float dinv[32];  // 1 / L[c][c], reused by the inverse
 #pragma unroll
             for (int c = 0; c < 32; ++c) {
-                const float d = rl(a[c], c);
+                const float d = rl(z[c], c);  // the pivot: lane c of the factor half
                 if (!(d > 0.0f) && bad == 0) bad = 32 * kb + c + 1;
                 // reciprocal square root + one Newton step (full fp32 accuracy) instead of an IEEE sqrt and 32 IEEE
                 // divisions per column: the factor does not need correctly rounded pivots, only accurate ones, and
                 // these two sequences were two thirds of the instruction count of this loop
                 float y = __builtin_amdgcn_rsqf(d);  // NaN for a negative pivot: the factor is visibly unusable
                 y = y * fmaf(-0.5f * d * y, y, 1.5f);
-                dinv[c] = y;
-                const float l = (r == c) ? d * y : a[c] * y;
-                a[c] = l;
+                const float l = (!inv && r == c) ? d * y : z[c] * y;  // factor: L[r][c]; inverse: x[c] = s[c] / L[c][c]
+                z[c] = l;
 #pragma unroll
-                for (int c2 = c + 1; c2 < 32; ++c2) a[c2] = fmaf(-l, rl(l, c2), a[c2]);
+                for (int c2 = c + 1; c2 < 32; ++c2) z[c2] = fmaf(-l, rl(l, c2), z[c2]);  // rl(l, c2) = L[c2][c], from the factor half
             }
             if (bad && lane == 0) atomicCAS(info, 0, j + bad);
-            // inverse, lane = column: x[q] = (delta - sum_{k<q} L[q][k] x[k]) / L[q][q]
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                float sacc = (r == q) ? 1.0f : 0.0f;
-#pragma unroll
-                for (int k = 0; k < q; ++k) sacc = fmaf(-rl(a[k], q), x[k], sacc);
-                x[q] = sacc * dinv[q];
-            }
-            if (lane < 32) {
-#pragma unroll
-                for (int c = 0; c < 32; ++c) {
-                    S[32 * kb + r][32 * kb + c] = (c <= r) ? a[c] : 0.0f;
-                    Xd[(kb * 32 + c) * XP + r] = x[c];  // X[row c][col r]
-                }
+            for (int c = 0; c < 32; ++c) {
+                if (!inv) S[32 * kb + r][32 * kb + c] = (c <= r) ? z[c] : 0.0f;
+                else Xd[(kb * 32 + c) * XP + r] = z[c];  // X[row c][col r]
             }
         }
         __syncthreads();

@@ -79,6 +79,7 @@ enum Opt : int {
     OPT_HESS_PARTS,
     OPT_GEMM_H16_BM,
     OPT_LUT_DENSE_M,
+    OPT_HESS_W4,
     OPT_COUNT
 };
 long long opt_get(int id);
@@ -91,6 +92,14 @@ int ensure_dynamic_lds(const void* func, size_t bytes);
 bool gemm_h16_supported(int64_t M, int64_t N, int64_t K);
 int gemm_h16(const void* x, const void* w, const void* bias, const float* addend, int dtype, int64_t M, int64_t N, int64_t K, void* y,
              hipStream_t stream);
+
+// Hessian of staged groups from TRANSPOSED activations Xt [in_features][ldt tokens], 256 x 256 tiles cut stream-K (hessian_w4.hip)
+const uint32_t* hessian_tile_table(int tiles, int* count);  // device table of the lower-triangular tile pairs (tu << 16 | tv), Z order
+bool hessian_w4_supported(int64_t n, int64_t ldt);
+size_t hessian_w4_workspace_bytes(int64_t n);
+int hessian_w4_stage(void* Xt, int64_t ldt, const void* X, int64_t rows, int64_t n, int64_t tok0, hipStream_t stream);
+int hessian_w4(float* H, const void* Xt, int64_t ldt, int dtype, int64_t rows, int64_t n, float decay, float scale, void* workspace,
+               size_t workspace_bytes, hipStream_t stream);
 
 // compute units of the CURRENT device (cached per device index; 0 on failure)
 int current_device_cus();

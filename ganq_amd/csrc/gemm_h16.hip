@@ -20,6 +20,7 @@
 //   * the two wave rows run ONE BARRIER APART, so that on every SIMD one wave issues matrix instructions while the other
 //     reads its fragments (v1, both rows in lockstep: 1.03 PF at 4096^3; see the kernel).
 #include "common.h"
+#include "mfma_h16.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -30,10 +31,6 @@ namespace {
 
 typedef _Float16 hg_f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 hg_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float hg_f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t hg_u32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(1))) void* hg_gptr;
-typedef __attribute__((address_space(3))) void* hg_lptr;
 
 constexpr int HBK = 64;    // in_features per K tile: one 128-byte line per row
 constexpr int HBN = 256;   // output features per workgroup
@@ -62,25 +59,6 @@ __device__ __forceinline__ void hg_tile_of(int bid, int tiles_m, int tiles_n, in
     const int ph = min(HG_PANEL, tiles_m - p * HG_PANEL);  // rows of tiles in this panel (the last one may be short)
     tn = idx / ph;
     tm = p * HG_PANEL + (idx - tn * ph);
-}
-
-// The same instruction with its accumulator PINNED to the accumulation registers ("+a"): with 256 of them per wave (four-wave kernel) hipcc
-// otherwise shuttles accumulator tiles between the two register files inside the K loop (1477 v_accvgpr moves and 242 spills in the
-// first build).  An asm statement is not reordered against other volatile asm, so the interleave below is the one written.
-template <bool BF16>
-__device__ __forceinline__ void hg_mfma_acc(hg_f32x4& acc, const hg_u32x4& a, const hg_u32x4& b) {
-    if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-
-// acc = 0, born in an accumulation register: a matrix instruction with the inline constant 0 as C and zero operands (a vector-register
-// zero copied in would make the loop's phi a vector register again)
-template <bool BF16>
-__device__ __forceinline__ void hg_mfma_zero(hg_f32x4& acc, const hg_u32x4& z) {
-    // (s_nop: the zero operand was written by a vector move right in front, and hipcc's hazard recogniser does not see a matrix
-    // instruction in an asm statement -- without the wait the first tile starts from the register's previous contents)
-    if constexpr (BF16) asm volatile("s_nop 4\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));
-    else asm volatile("s_nop 4\n\tv_mfma_f32_16x16x32_f16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));
 }
 
 template <bool BF16, int BM>
@@ -327,7 +305,7 @@ __global__ __launch_bounds__(HTHREADS, 1) void gemm_h16_kernel(const uint16_t* _
 //   * rows are 64 B in LDS; the 16-byte slot is XORed with (row >> 2) & 3: the 16 lanes of a quarter wave read 16 different
 //     16-byte bank groups (LDS-DMA writes lane-linear, so the permutation is applied to the global source slot).
 #ifdef HG_PROBE
-// developer build only (-DHG_PROBE, tools/dev/gemm_probe.sh): cycle counts of the four waves of workgroup 0, summed over the slices
+// developer build only (-DHG_PROBE, tools/dev/probe_build.sh): cycle counts of the four waves of workgroup 0, summed over the slices
 __device__ unsigned long long hg_probe_buf[4 * 8];
 #define HG_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #else

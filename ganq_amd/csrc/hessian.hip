@@ -478,6 +478,12 @@ const uint32_t* tile_table(int tiles, int mh, int* count) {
     return dev;
 }
 
+}  // namespace
+// (for hessian_w4.hip: the same table for its 256 x 256 tiles -- 32 consecutive entries of the Z curve are a 4 x 8 / 8 x 4 block)
+namespace ganq {
+const uint32_t* hessian_tile_table(int tiles, int* count) { return tile_table(tiles, 1, count); }
+}  // namespace ganq
+namespace {
 // scratch of the token-split launches (partial tiles): caller-owned, see ganq_hessian_workspace_bytes
 inline size_t sk_scratch_bytes(int ncu) { return (size_t)6 * (size_t)ncu * HT * HT * sizeof(float); }  // 6 ncu x 64 KB = 3 ncu x 128 KB (96 MB)
 }  // namespace
@@ -603,4 +609,30 @@ extern "C" int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t ro
         done += piece;
     } while (done < rows);
     return 0;
+}
+
+/* ---- the transposed staging path (hessian_w4.hip): the host stages the calibration batches of a group as Xt [in_features][ldt tokens]
+ * (ganq_hessian_stage_t per batch: the copy it made anyway, now transposing) and hands the group over once. ---- */
+extern "C" int ganq_hessian_t_supported(int64_t n, int64_t ldt) { return hessian_w4_supported(n, ldt) ? 1 : 0; }
+
+extern "C" size_t ganq_hessian_t_workspace_bytes(int64_t n) { return n > 0 ? hessian_w4_workspace_bytes(n) : 0; }
+
+extern "C" int ganq_hessian_stage_t(void* Xt, int64_t ldt, const void* X, int64_t rows, int64_t n, int64_t tok0, void* stream_) {
+    if (rows < 0 || n <= 0 || tok0 < 0 || ldt <= 0) return fail(-1, "ganq_hessian_stage_t: bad sizes");
+    if (!Xt || (!X && rows > 0)) return fail(-3, "ganq_hessian_stage_t: null pointer");
+    return hessian_w4_stage(Xt, ldt, X, rows, n, tok0, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int ganq_hessian_accum_t(float* H, const void* Xt, int64_t ldt, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
+                                    int64_t batch, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (rows < 0 || n < 0 || nsamples_before < 0 || batch <= 0) return fail(-1, "ganq_hessian_accum_t: bad sizes");
+    if (n == 0 || rows == 0) return rows == 0 && n > 0 ? fail(-1, "ganq_hessian_accum_t: an empty group") : 0;
+    if (dtype != 0 && dtype != 1) return fail(-2, "ganq_hessian_accum_t: dtype %d (0 = fp16, 1 = bf16)", dtype);
+    if (!H || !Xt) return fail(-3, "ganq_hessian_accum_t: null pointer");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const double total = (double)(nsamples_before + batch);
+    const float decay = (float)((double)nsamples_before / total);
+    const float scale = (float)(2.0 / total);
+    ProfScope prof(KID_HESSIAN, stream);
+    return hessian_w4(H, Xt, ldt, dtype, rows, n, decay, scale, workspace, workspace_bytes, stream);
 }

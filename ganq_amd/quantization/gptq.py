@@ -83,7 +83,8 @@ class GPTQ:
         # n = 4096) is read-modify-written once per group instead of once per sequence, and the kernel's main loop is
         # eight times longer per tile.  0 turns the staging off.
         self.hessian_stage_tokens = int(getattr(self.qcfg, "ganq_hessian_stage_tokens", 16384) or 0)
-        self._stage = None        # [capacity, columns] in the activations' dtype
+        self._stage = None        # [capacity, columns] in the activations' dtype -- or, round 4, TRANSPOSED [columns, capacity]
+        self._stage_t = False     # (layers the transposed Hessian kernel serves: the staging copy transposes, _lib.hessian_stage_t)
         self._stage_holder = None
         self._stage_rows = 0
         self._stage_seqs = 0
@@ -128,13 +129,22 @@ class GPTQ:
         if inp.dtype in (torch.float16, torch.bfloat16):
             rows = inp.shape[0]
             if self.hessian_stage_tokens > 0 and rows < self.hessian_stage_tokens:
-                if self._stage is not None and (self._stage.dtype != inp.dtype or self._stage_rows + rows > self._stage.shape[0]):
+                if self._stage is not None and (self._stage.dtype != inp.dtype or self._stage_rows + rows > self.hessian_stage_tokens):
                     self._flush_stage()
                 if (self._stage is None or self._stage.dtype != inp.dtype) and not self._stage_acquire(inp.dtype):
                     _lib.hessian_accum(self.H, inp, self.nsamples, batch)  # the device already holds STAGE_MAX_LIVE buffers
                     self.nsamples += batch
                     return
-                self._stage[self._stage_rows:self._stage_rows + rows].copy_(inp)
+                if self._stage_t and (rows % 8 or self._stage_rows % 8):
+                    # (the transposing copy moves whole groups of 8 tokens; a ragged batch ends the group and goes alone)
+                    self._flush_stage()
+                    _lib.hessian_accum(self.H, inp, self.nsamples, batch)
+                    self.nsamples += batch
+                    return
+                if self._stage_t:
+                    _lib.hessian_stage_t(self._stage, inp, self._stage_rows)
+                else:
+                    self._stage[self._stage_rows:self._stage_rows + rows].copy_(inp)
                 self._stage_rows += rows
                 self._stage_seqs += batch
                 self.nsamples += batch
@@ -159,7 +169,9 @@ class GPTQ:
         live = _STAGE_LIVE.setdefault(key, weakref.WeakSet())
         if len(live) >= STAGE_MAX_LIVE:
             return False
-        self._stage_holder = _StageBuffer(torch.empty((self.hessian_stage_tokens, self.columns), dtype=dtype, device=self.device))
+        self._stage_t = _lib.hessian_t_supported(self.columns, self.hessian_stage_tokens, self.device)
+        shape = (self.columns, self.hessian_stage_tokens) if self._stage_t else (self.hessian_stage_tokens, self.columns)
+        self._stage_holder = _StageBuffer(torch.empty(shape, dtype=dtype, device=self.device))
         self._stage = self._stage_holder.tensor
         live.add(self._stage_holder)
         return True
@@ -185,7 +197,13 @@ class GPTQ:
         """send the staged calibration batches to the Hessian kernel as one group (see __init__)"""
         if self._stage_rows:
             before = self.nsamples - self._stage_seqs  # self.nsamples already counts the staged sequences
-            _lib.hessian_accum(self.H, self._stage[:self._stage_rows], before, self._stage_seqs)
+            if self._stage_t:
+                rows = -(-self._stage_rows // 32) * 32  # the kernel walks slices of 32 tokens: a ragged last one is zero-filled
+                if rows != self._stage_rows:
+                    self._stage[:, self._stage_rows:rows].zero_()
+                _lib.hessian_accum_t(self.H, self._stage, rows, before, self._stage_seqs)
+            else:
+                _lib.hessian_accum(self.H, self._stage[:self._stage_rows], before, self._stage_seqs)
             self._stage_rows = 0
             self._stage_seqs = 0
 

@@ -72,6 +72,23 @@ size_t ganq_hessian_workspace_bytes(int64_t rows, int64_t n);
 int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
                        int64_t batch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- a1, staged groups from TRANSPOSED activations (round 4).  The reference multiplies every batch as it arrives
+ * (gptq.py:122-131: inp.t() in [in_features, tokens] layout, `self.H += inp.matmul(inp.t())`).  H telescopes over a
+ * group of batches, so the host stages them and hands the group over once -- and because the matrix cores want the
+ * TOKENS of a feature contiguous (the layout of the reference's `inp` after its `.t()`), the staging copy transposes:
+ *     ganq_hessian_stage_t:  Xt[:, tok0 : tok0 + rows] = X^T          X [rows, n] one batch, Xt [n, ldt] fp16 / bf16
+ *     ganq_hessian_accum_t:  H <- H * N/(N+batch) + (2/(N+batch)) * Xt[:, :rows] Xt[:, :rows]^T
+ * rows of accum_t: a multiple of 32 (the host zero-fills the columns of a ragged last slice); tok0, rows of stage_t and
+ * n: multiples of 8.  ganq_hessian_t_supported(n, ldt) says whether a layer is served (in_features >= 1024, a multiple
+ * of 8, n * ldt * 2 B < 4 GiB); otherwise the host stages row-major and calls ganq_hessian_accum.  workspace:
+ * ganq_hessian_t_workspace_bytes(n) of caller-owned scratch (ticket counters + two partial tiles per compute unit).
+ * Same products as ganq_hessian_accum, another grouping of the fp32 sums; exactly symmetric; deterministic.       */
+int ganq_hessian_t_supported(int64_t n, int64_t ldt);
+size_t ganq_hessian_t_workspace_bytes(int64_t n);
+int ganq_hessian_stage_t(void* Xt, int64_t ldt, const void* X, int64_t rows, int64_t n, int64_t tok0, void* stream);
+int ganq_hessian_accum_t(float* H, const void* Xt, int64_t ldt, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
+                         int64_t batch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a2: prologue (gptq.py:280-309) -- lower Cholesky factor A = L L^T in fp32, in place (row-major, leading
  * dimension lda; the strictly upper triangle is zeroed like torch.linalg.cholesky does).  *info (device int32) is 0
  * on success or the 1-based column of the first non-positive pivot (the factor then holds NaN); nothing is

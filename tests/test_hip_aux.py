@@ -127,6 +127,70 @@ def test_hessian_token_split_launches(hip, rows, n, dtype, lib_options):
         assert torch.equal(H, outs[cfg]), cfg
 
 
+@pytest.mark.parametrize("rows,n,dtype", [(4096, 1024, torch.float16), (8192, 2048, torch.bfloat16), (16384, 4096, torch.float16),
+                                          (4096, 1288, torch.float16), (6144, 3072, torch.bfloat16), (4128, 2048, torch.float16),
+                                          (2048, 4096, torch.float16), (40, 1024, torch.float16)])
+def test_hessian_transposed_staging_stream_k(hip, rows, n, dtype):
+    """hessian_w4.hip: the batches of a group staged TRANSPOSED (hessian_stage_t, one call per batch) and multiplied as Xt Xt^T with
+    256 x 256 tiles, the (tile, token slice) pairs cut into equal shares, one per CU; partial tiles meet through a ticket and are
+    summed in range order.  Against the fp64 product and the row-major kernels (same products, another grouping of the fp32 sums);
+    exactly symmetric; the same bits from run to run whichever workgroup finishes a tile; the running average's decay applied
+    once; in_features that are not a multiple of the tile (1288), token counts that are not a multiple of the slice (4128 -> the
+    host zero-fills, 40), a group that fills only part of the staging buffer."""
+    g = torch.Generator().manual_seed(rows + n)
+    X1 = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
+    X2 = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
+    cap = -(-rows // 32) * 32 + 64  # (the buffer is larger than the group)
+    assert hip.hessian_t_supported(n, cap)
+
+    def run():
+        H = torch.full((n, n), 7.0, device="cuda")  # stale contents must be ignored on the first batch
+        Xt = torch.full((n, cap), 3.0, dtype=dtype, device="cuda")  # stale tokens behind the group must not count
+        pad = -(-rows // 32) * 32
+        for X, before, batch in ((X1, 0, 2), (X2, 2, 3)):
+            step = max(8, rows // 3 // 8 * 8)  # three or four batches per group
+            for t0 in range(0, rows, step):
+                hip.hessian_stage_t(Xt, X[t0:t0 + step], t0)
+            Xt[:, rows:pad].zero_()
+            hip.hessian_accum_t(H, Xt, pad, before, batch)
+        return H
+
+    H = run()
+    Hr = torch.full((n, n), 7.0, device="cuda")
+    hip.hessian_accum(Hr, X1, 0, 2)
+    hip.hessian_accum(Hr, X2, 2, 3)              # H * 2/5 + (2/5) X2^T X2
+    ref = (2.0 / 5.0) * (X1.double().T @ X1.double() + X2.double().T @ X2.double())
+    assert torch.equal(H, H.T)
+    assert float((H.double() - ref).norm() / ref.norm()) < 1e-6
+    assert float((H - Hr).abs().max() / Hr.abs().max()) < 1e-5
+    for _ in range(3):  # deterministic
+        assert torch.equal(run(), H)
+
+
+def test_hessian_transposed_staging_in_the_quantizer(hip):
+    """GPTQ.add_batch stages transposed where the layer is served (n >= 1024) and row-major elsewhere: the same Hessian as batch-by-batch
+    accumulation, ragged batches and a dtype change inside the calibration included"""
+    from ganq_amd.quantization import GANQ, QuantizeConfig
+    from ganq_amd.looper.named_module import NamedModule
+
+    n = 1024
+    lin = torch.nn.Linear(n, 32, bias=False).half().cuda()
+    g = torch.Generator().manual_seed(3)
+    xs = [(torch.randn(1, t, n, generator=g) * 0.5).half().cuda() for t in (256, 256, 200, 256, 4, 256, 36)]
+    Hs = {}
+    for stage in (0, 1024):
+        q = GANQ(NamedModule(lin, "fc", "layers.0.fc", 0), QuantizeConfig(bits=4, ganq_hessian_stage_tokens=stage))
+        q.quantizer.configure(perchannel=True)
+        for x in xs:
+            q.add_batch(x, None)
+        Hs[stage] = q.hessian.clone()
+        assert q.nsamples == len(xs)
+        assert stage == 0 or q._stage_t
+        q.free() if hasattr(q, "free") else None
+    assert torch.equal(Hs[1024], Hs[1024].T)
+    assert float((Hs[1024] - Hs[0]).abs().max() / Hs[0].abs().max()) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ Cholesky (prologue)
 @pytest.mark.parametrize("n", [1, 5, 127, 128, 129, 300, 1000, 2048])
 def test_cholesky_vs_fp64(hip, n):

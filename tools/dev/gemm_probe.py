@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""developer: where the four-wave GEMM's cycles go (GANQ_HIP_LIB=build_variants/libganq_probe.so, built by tools/dev/gemm_probe.sh)"""
+"""developer: where the four-wave GEMM's cycles go (GANQ_HIP_LIB=build_variants/libganq_probe.so, built by tools/dev/probe_build.sh gemm_h16 HG_PROBE)"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ganq_amd import _lib
