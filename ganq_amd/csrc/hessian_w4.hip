@@ -45,24 +45,26 @@ __device__ __forceinline__ void hw_tile_of(const uint32_t* __restrict__ table, i
     bv = (int)(e & 0xffffu);
 }
 
-// The staging copy, transposing: Xt[f][tok0 + t] = X[t][f] for one calibration batch X [rows][n].  64 tokens x 128 features per
+// The staging copy, transposing: Xt[f][tok0 + t] = X[t][f] for one calibration batch X [rows][n].  128 tokens x 128 features per
 // workgroup through LDS, 16-byte loads along the features, transposed reads (ds_read_b64_tr_b16: a 16-lane group takes a 4 x 16 block and
 // hands every lane 4 tokens of one feature), 16-byte stores along the tokens -- four lanes write 64 contiguous bytes of a feature
 // row, workgroups that run side by side (token tiles vary fastest) the neighbouring lines of the same rows.  Tokens past `rows` are
 // neither read nor written (groups of 8: tok0 and rows are multiples of 8).
 constexpr int WTP = 144;  // LDS pitch in 16-bit elements (288 B)
+constexpr int WTT = 128;  // tokens per workgroup (eight 16-byte loads per thread in flight; 64: 3.0 TB/s, 128: see DESIGN.md)
 __global__ __launch_bounds__(256) void hw_stage_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Xt, int rows, int n, int64_t ldt) {
-    __shared__ __align__(16) uint16_t S[64][WTP];
+    __shared__ __align__(16) uint16_t S[WTT][WTP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tok0 = blockIdx.x * 64, f0 = blockIdx.y * 128;
-    uint4 v[4];
+    const int tok0 = blockIdx.x * WTT, f0 = blockIdx.y * 128;
+    constexpr int NL = WTT * 16 / 256;  // 16-byte pieces per thread
+    uint4 v[NL];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NL; ++k) {
         const int id = tid + 256 * k, row = id >> 4, col = (id & 15) * 8;
         v[k] = (tok0 + row < rows && f0 + col < n) ? *reinterpret_cast<const uint4*>(X + (size_t)(tok0 + row) * n + f0 + col) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NL; ++k) {
         const int id = tid + 256 * k, row = id >> 4, col = (id & 15) * 8;
         *reinterpret_cast<uint4*>(&S[row][col]) = v[k];
     }
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void hw_stage_kernel(const uint16_t* __restric
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < WTT / 32; ++h) {
             const int fb = 32 * wv + 16 * blk;
             const hw_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)&S[32 * h + 8 * g + q][fb + 4 * p]);
             const hw_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)&S[32 * h + 8 * g + q + 4][fb + 4 * p]);
@@ -349,19 +351,28 @@ __global__ __launch_bounds__(256) void hessian_w4_fix_kernel(float* __restrict__
         hg_f32x4 sum[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum[e] = hg_f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int pi = 0; pi < np; ++pi) {
-            int cc = r, sl = 0;
-            if (pi >= pb) {
-                const int h = hf + pi - pb;
-                cc = nprim + h;
-                sl = r - (int)(((long long)h * Sh) / Lt);
+        for (int pi0 = 0; pi0 < np; pi0 += 3) {  // three parts per round trip (the usual tile has two or three)
+            hg_f32x4 v[3][8];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int pi = pi0 + d;
+                if (pi >= np) continue;
+                int cc = r, sl = 0;
+                if (pi >= pb) {
+                    const int h = hf + pi - pb;
+                    cc = nprim + h;
+                    sl = r - (int)(((long long)h * Sh) / Lt);
+                }
+                const float* src = partial + ((size_t)cc * W_SLOTS + sl) * W_PART + (size_t)wvq * (W_PART / 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[d][e] = *reinterpret_cast<const hg_f32x4*>(src + (size_t)((half * 8 + e) * 256 + tid) * 4);
             }
-            const float* src = partial + ((size_t)cc * W_SLOTS + sl) * W_PART + (size_t)wvq * (W_PART / 4);
-            hg_f32x4 v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const hg_f32x4*>(src + (size_t)((half * 8 + e) * 256 + tid) * 4);
+            for (int d = 0; d < 3; ++d) {
+                if (pi0 + d >= np) continue;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sum[e] += v[e];
+                for (int e = 0; e < 8; ++e) sum[e] += v[d][e];
+            }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -390,7 +401,9 @@ __global__ __launch_bounds__(256) void hessian_w4_fix_kernel(float* __restrict__
 
 // layers the transposed path serves: whole 16-byte pieces per token row / feature row, 32-bit offsets into Xt
 bool hessian_w4_supported(int64_t n, int64_t ldt) {
-    if (n < 1024 || (n % 8) != 0 || ldt < WSK || (ldt % WSK) != 0 || current_device_cus() < 8) return false;
+    // (from 3072 in_features on: below, the 128 x 128 kernels of hessian.hip are as fast or faster -- n = 2048: 128 against 137 us per 16384
+    // tokens, n = 1024: 90 against 78 -- and keep the plain staging copy; GANQ_HESS_W4 = 2 (tests) lowers the bar to 1024)
+    if (n < (opt_get(OPT_HESS_W4) == 2 ? 1024 : 3072) || (n % 8) != 0 || ldt < WSK || (ldt % WSK) != 0 || current_device_cus() < 8) return false;
     const int64_t nt = (n + WT - 1) / WT;
     return nt * (nt + 1) / 2 <= W_MAX_TILES && n * ldt * 2 < ((int64_t)1 << 32) && opt_get(OPT_HESS_W4) != 0;
 }
@@ -406,7 +419,7 @@ int hessian_w4_stage(void* Xt, int64_t ldt, const void* X, int64_t rows, int64_t
         return fail(-1, "ganq_hessian_stage_t: tokens %lld + %lld of %lld, in_features %lld (multiples of 8 expected)", (long long)tok0, (long long)rows,
                     (long long)ldt, (long long)n);
     if ((reinterpret_cast<uintptr_t>(X) & 15) != 0 || (reinterpret_cast<uintptr_t>(Xt) & 15) != 0) return fail(-3, "ganq_hessian_stage_t: 16-byte aligned buffers expected");
-    hipLaunchKernelGGL(hw_stage_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((n + 127) / 128)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(hw_stage_kernel, dim3((unsigned)((rows + WTT - 1) / WTT), (unsigned)((n + 127) / 128)), dim3(256), 0, stream,
                        static_cast<const uint16_t*>(X), static_cast<uint16_t*>(Xt) + tok0, (int)rows, (int)n, (int64_t)ldt);
     GANQ_LAUNCH_CHECK();
     return 0;

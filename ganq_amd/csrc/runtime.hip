@@ -59,7 +59,7 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"GANQ_HESS_PARTS", 0},        // Hessian, developer: cut the tiles behind the bulk into exactly this many parts (0: as many as fill the free slots)
     {"GANQ_GEMM_H16_BM", 0},       // dense GEMM of the LUT forward: force 128- / 256-row tiles (0: by tile count)
     {"GANQ_LUT_DENSE_M", -1},      // LUT forward: from this many rows of x on, dequantise once + dense GEMM (-1: by shape; 0: never)
-    {"GANQ_HESS_W4", 1},           // Hessian, staged groups: 0 = never the 256 x 256 stream-K kernel (hessian_w4.hip)
+    {"GANQ_HESS_W4", 1},           // Hessian, staged groups: 0 = never the transposed staging + 256 x 256 stream-K kernel (hessian_w4.hip); 2 = from 1024 in_features on (default: 3072)
 };
 
 std::atomic<long long> g_opt[OPT_COUNT];

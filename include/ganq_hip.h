@@ -79,7 +79,7 @@ int ganq_hessian_accum(float* H, const void* X, int dtype, int64_t rows, int64_t
  *     ganq_hessian_stage_t:  Xt[:, tok0 : tok0 + rows] = X^T          X [rows, n] one batch, Xt [n, ldt] fp16 / bf16
  *     ganq_hessian_accum_t:  H <- H * N/(N+batch) + (2/(N+batch)) * Xt[:, :rows] Xt[:, :rows]^T
  * rows of accum_t: a multiple of 32 (the host zero-fills the columns of a ragged last slice); tok0, rows of stage_t and
- * n: multiples of 8.  ganq_hessian_t_supported(n, ldt) says whether a layer is served (in_features >= 1024, a multiple
+ * n: multiples of 8.  ganq_hessian_t_supported(n, ldt) says whether a layer is served (in_features >= 3072, a multiple
  * of 8, n * ldt * 2 B < 4 GiB); otherwise the host stages row-major and calls ganq_hessian_accum.  workspace:
  * ganq_hessian_t_workspace_bytes(n) of caller-owned scratch (ticket counters + two partial tiles per compute unit).
  * Same products as ganq_hessian_accum, another grouping of the fp32 sums; exactly symmetric; deterministic.       */

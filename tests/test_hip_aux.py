@@ -130,7 +130,7 @@ def test_hessian_token_split_launches(hip, rows, n, dtype, lib_options):
 @pytest.mark.parametrize("rows,n,dtype", [(4096, 1024, torch.float16), (8192, 2048, torch.bfloat16), (16384, 4096, torch.float16),
                                           (4096, 1288, torch.float16), (6144, 3072, torch.bfloat16), (4128, 2048, torch.float16),
                                           (2048, 4096, torch.float16), (40, 1024, torch.float16)])
-def test_hessian_transposed_staging_stream_k(hip, rows, n, dtype):
+def test_hessian_transposed_staging_stream_k(hip, rows, n, dtype, lib_options):
     """hessian_w4.hip: the batches of a group staged TRANSPOSED (hessian_stage_t, one call per batch) and multiplied as Xt Xt^T with
     256 x 256 tiles, the (tile, token slice) pairs cut into equal shares, one per CU; partial tiles meet through a ticket and are
     summed in range order.  Against the fp64 product and the row-major kernels (same products, another grouping of the fp32 sums);
@@ -141,6 +141,7 @@ def test_hessian_transposed_staging_stream_k(hip, rows, n, dtype):
     X1 = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
     X2 = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
     cap = -(-rows // 32) * 32 + 64  # (the buffer is larger than the group)
+    lib_options(GANQ_HESS_W4=2)     # (the product takes this path from 3072 in_features on)
     assert hip.hessian_t_supported(n, cap)
 
     def run():
@@ -167,13 +168,14 @@ def test_hessian_transposed_staging_stream_k(hip, rows, n, dtype):
         assert torch.equal(run(), H)
 
 
-def test_hessian_transposed_staging_in_the_quantizer(hip):
+def test_hessian_transposed_staging_in_the_quantizer(hip, lib_options):
     """GPTQ.add_batch stages transposed where the layer is served (n >= 1024) and row-major elsewhere: the same Hessian as batch-by-batch
     accumulation, ragged batches and a dtype change inside the calibration included"""
     from ganq_amd.quantization import GANQ, QuantizeConfig
     from ganq_amd.looper.named_module import NamedModule
 
     n = 1024
+    lib_options(GANQ_HESS_W4=2)
     lin = torch.nn.Linear(n, 32, bias=False).half().cuda()
     g = torch.Generator().manual_seed(3)
     xs = [(torch.randn(1, t, n, generator=g) * 0.5).half().cuda() for t in (256, 256, 200, 256, 4, 256, 36)]

@@ -17,6 +17,18 @@ for n in (4096, 2048, 8192, 14336):
         us = ms / cnt * 1e3
         print(f"n={n} rows={rows}: {us:.1f} us per launch = {us * 2048 / rows:.1f} us per 2048 tokens -> "
               f"{2.0 * rows * n * n / (us * 1e-6) / 1e12:.0f} TFLOP/s ({2.0 * rows * n * n / (us * 1e-6) / 2.5e15:.2f} of the 2.5 PF fp16 peak)", flush=True)
+        if _lib.hessian_t_supported(n, rows):  # the transposed staging path (hessian_w4.hip): the group as Xt [n, rows]
+            Xt = X.t().contiguous()
+            for _ in range(2): _lib.hessian_accum_t(H, Xt, rows, ns, rows // 2048); ns += rows // 2048
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            for _ in range(5): _lib.hessian_accum_t(H, Xt, rows, ns, rows // 2048); ns += rows // 2048
+            rep = _lib.profile_report(); _lib.profile_enable(False)
+            ms, cnt = rep["hessian_kernel"]
+            ut = ms / cnt * 1e3
+            print(f"n={n} rows={rows}, transposed staging: {ut:.1f} us per group = {ut * 2048 / rows:.1f} us per 2048 tokens -> "
+                  f"{2.0 * rows * n * n / (ut * 1e-6) / 1e12:.0f} TFLOP/s nominal, {1.0 * rows * n * n / (ut * 1e-6) / 1e15:.2f} PF executed ({us / ut:.2f} x the row-major kernels)", flush=True)
+            del Xt
         del X, H
 import torch.nn as nn
 from ganq_amd.looper.named_module import NamedModule
