@@ -93,16 +93,33 @@ __device__ __forceinline__ void load_block(float (*dst)[CP], const float* __rest
 // row per lane in registers (pivot / column broadcasts are v_readlane, no LDS round trips) and inverts it in the same
 // instructions (one column of the inverse per lane of the upper half wave); the blocks below are multiplied by that inverse and the trailing blocks
 // updated on the matrix cores.  Only the four 32x32 inverses leave the kernel: the panel kernel solves block-wise.
-__global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, int64_t lda, int j, int nb,
+// jprev >= 0 (look-ahead driver): the block has not yet received the PREVIOUS step's update -- it is applied here, S -= P P^T with
+// P = A[j.., jprev .. jprev + 128) (that step's first panel block), so that this kernel depends on the previous panel kernel only
+// and the previous step's whole trailing update runs beside it on the second stream.
+__global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, int64_t lda, int j, int nb, int jprev,
                                                         float* __restrict__ Xout, int* __restrict__ info) {
     extern __shared__ __align__(16) float sm[];
     float(*S)[CP] = reinterpret_cast<float(*)[CP]>(sm);  // the block, lower part
     float* Xd = sm + CB * CP;                              // [4][32][XP]
+    float(*Pp)[CP] = reinterpret_cast<float(*)[CP]>(sm + CB * CP + 4 * 32 * XP);  // (jprev >= 0 only: the launch then has the LDS for it)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (jprev >= 0) load_block(Pp, A, lda, j, nb, jprev, CB, tid, false);
     // (all 16 row segments of a thread in flight at once: the element-wise loop this replaces was 64 dependent round trips to
     // L2 -- a third of the kernel's 64 us in round 3)
     load_block(S, A, lda, j, nb, j, nb, tid, true);
     __syncthreads();
+    if (jprev >= 0) {  // the ten 32 x 32 blocks of the lower triangle, K = 128, dealt over the four waves
+        int p = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int jb = 0; jb <= i; ++jb, ++p) {
+                if ((p & 3) != wv) continue;
+                f32x16 acc;
+                acc_load(acc, &S[32 * i][32 * jb], CP, lane);
+                for (int k = 0; k < 4; ++k) mm32(acc, &Pp[32 * i][32 * k], CP, &Pp[32 * jb][32 * k], CP, true, lane);
+                acc_store(acc, &S[32 * i][32 * jb], CP, lane);
+            }
+        __syncthreads();
+    }
     if (tid >= nb && tid < CB) S[tid][tid] = 1.0f;  // a short last block is padded with the identity
     __syncthreads();
     for (int kb = 0; kb < 4; ++kb) {
@@ -206,7 +223,8 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(float* __restrict__ A, 
 // Update: tile (bi >= bj) of the trailing matrix at R0 = j + nb: A22[bi][bj] -= L21[bi] L21[bj]^T, K = nb <= 128 held
 // entirely in LDS, 4 waves x (64x64).
 // part 0: every tile; part 1: only the first block column (what the next diagonal block and panel read); part 2: the
-// tiles right of it -- the driver runs part 2 on a second stream next to the next step's diagonal / panel kernels.
+// tiles right of it; part 3: the first block column below its diagonal tile -- the look-ahead driver runs parts 3 and 2 on a second
+// stream next to the next step's diagonal / panel kernels.
 __global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ A, int64_t lda, int n, int j, int nb, int part) {
     extern __shared__ __align__(16) float sm[];
     float(*As)[CP] = reinterpret_cast<float(*)[CP]>(sm);
@@ -216,8 +234,8 @@ __global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ A,
     // linear index -> (bi, bj) with bj <= bi
     const int t = blockIdx.x;
     int bi, bj;
-    if (part == 1) {
-        bi = t;
+    if (part == 1 || part == 3) {  // 3: the first block column WITHOUT its diagonal tile (the next diagonal kernel applies that one itself)
+        bi = t + (part == 3 ? 1 : 0);
         bj = 0;
     } else {
         bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -254,22 +272,31 @@ __global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ A,
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
-    // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Read-modify-write of the tile: ALL 64 old values of a lane are requested before the first store (as a loop of `*p -= acc`
+    // the compiler keeps every load behind the previous store -- it cannot know they do not alias -- and the tile's end was 64
+    // round trips to L2: 33 us for a launch of one round of tiles whose matrix work is 7 us).
+    float oldv[2][2][16];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rr = wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                const int cc = wn + 32 * b + i32;
-                const int row = ra0 + rr;
-                if (row >= n) continue;
-                const int col = rb0 + cc;
-                if (col < n && col <= row) {
-                    float* p = A + (int64_t)row * lda + col;
-                    *p = *p - acc[a][b][e];
-                }
+                const int row = ra0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                const int col = rb0 + wn + 32 * b + i32;
+                const bool ok = row < n && col < n && col <= row;
+                oldv[a][b][e] = ok ? __builtin_nontemporal_load(A + (int64_t)row * lda + col) : 0.0f;
+            }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = ra0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                const int col = rb0 + wn + 32 * b + i32;
+                if (row < n && col < n && col <= row) A[(int64_t)row * lda + col] = oldv[a][b][e] - acc[a][b][e];
             }
 }
 
@@ -292,7 +319,7 @@ extern "C" size_t ganq_cholesky_workspace_bytes(int64_t n) {
 namespace {
 struct Lookahead {
     hipStream_t side;
-    hipEvent_t col_done, rest_done;
+    hipEvent_t panel_done, col_done, rest_done[2];
 };
 // one helper stream + two events per (device, caller stream), created on first use: two factorisations may run at
 // the same time on different streams (the prologue does that).  GANQ_CHOL_LOOKAHEAD=0 turns the second stream off.
@@ -314,8 +341,10 @@ Lookahead* lookahead_for(hipStream_t main) {
     if (used == 32) return nullptr;  // more caller streams than slots: plain single-stream factorisation
     Lookahead la{};
     if (hipStreamCreateWithFlags(&la.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&la.col_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&la.rest_done, hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&la.panel_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&la.col_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&la.rest_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&la.rest_done[1], hipEventDisableTiming) != hipSuccess)
         return nullptr;
     slots[used] = Slot{dev, main, la};
     return &slots[used++].la;
@@ -345,38 +374,53 @@ extern "C" int ganq_cholesky(float* A, int64_t n, int64_t lda, int32_t* info_out
     }
     ProfScope prof(KID_CHOLESKY, stream);
     GANQ_HIP_CHECK(hipMemsetAsync(info_out, 0, sizeof(int32_t), stream));
-    // Look-ahead: the diagonal block and the panel of step j+1 only need the first block column of step j's trailing
-    // update.  That column is updated first; the rest of the update runs on a second stream next to the (single
-    // workgroup, latency-bound) diagonal kernel and the panel kernel of the next step.
+    // Look-ahead (n >= 4096): the chain diagonal -> panel -> diagonal -> ... runs on the caller's stream and touches the trailing
+    // matrix only through the panel: the diagonal kernel of step s + 1 applies step s's update to its own block itself (from the first
+    // panel block), the panel kernel of step s + 1 waits for the first block column of step s's update, and the whole update of step
+    // s -- first column, then the rest -- runs on a second stream beside them.  Round 3 kept the first block column on the chain
+    // (diag 64 + panel 21 + column 26 us per step and the launch gaps between them: 4.05 ms at n = 4096).
     Lookahead* la = lookahead_for(stream);
-    // measured on MI355X: n = 2048 1.97 ms with / 1.84 without, 4096 4.05 / 4.14, 8192 11.6 / 13.0 (the two event hops
-    // per step cost about as much as the overlap gains below n = 4096)
     const bool two = la != nullptr && n >= 32 * CB;
-    for (int64_t j = 0; j < n; j += CB) {
+    if (two) {
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(chol_diag_kernel), smem_diag + (size_t)CB * CP * sizeof(float));
+        if (rc) return rc;
+    }
+    int step = 0;
+    for (int64_t j = 0; j < n; j += CB, ++step) {
         const int nb = (int)std::min<int64_t>(CB, n - j);
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), smem_diag, stream, A, lda, (int)j, nb, X, info_out);
         const int64_t rem = n - j - nb;
+        const int nblk = (int)((rem + CB - 1) / CB);
+        if (!two) {
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), smem_diag, stream, A, lda, (int)j, nb, -1, X, info_out);
+            if (rem > 0) {
+                hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), smem_panel, stream, A, lda, (int)n, (int)j, nb, X);
+                hipLaunchKernelGGL(chol_update_kernel, dim3(nblk * (nblk + 1) / 2), dim3(256), smem, stream, A, lda, (int)n, (int)j, nb, 0);
+            }
+            continue;
+        }
+        // this step's diagonal block was last written by the rest-update of step - 2 (second stream)
+        if (step >= 2) GANQ_HIP_CHECK(hipStreamWaitEvent(stream, la->rest_done[step & 1], 0));
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), smem_diag + (step > 0 ? (size_t)CB * CP * sizeof(float) : 0), stream, A, lda, (int)j, nb,
+                           step > 0 ? (int)(j - CB) : -1, X, info_out);
         if (rem > 0) {
-            const int nblk = (int)((rem + CB - 1) / CB);
+            // the panel's rows were last written by the first block column of the previous step's update (second stream)
+            if (step >= 1) GANQ_HIP_CHECK(hipStreamWaitEvent(stream, la->col_done, 0));
             hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), smem_panel, stream, A, lda, (int)n, (int)j, nb, X);
-            if (!two) {
-                hipLaunchKernelGGL(chol_update_kernel, dim3(nblk * (nblk + 1) / 2), dim3(256), smem, stream, A, lda, (int)n,
-                                   (int)j, nb, 0);
-                continue;
-            }
-            // the previous step's rest-update (second stream) wrote the tiles this step's updates read-modify-write
-            if (j > 0) GANQ_HIP_CHECK(hipStreamWaitEvent(stream, la->rest_done, 0));
-            hipLaunchKernelGGL(chol_update_kernel, dim3(nblk), dim3(256), smem, stream, A, lda, (int)n, (int)j, nb, 1);
-            if (nblk > 1) {
-                GANQ_HIP_CHECK(hipEventRecord(la->col_done, stream));  // the panel of this step is complete as well
-                GANQ_HIP_CHECK(hipStreamWaitEvent(la->side, la->col_done, 0));
-                hipLaunchKernelGGL(chol_update_kernel, dim3((nblk - 1) * nblk / 2), dim3(256), smem, la->side, A, lda, (int)n,
-                                   (int)j, nb, 2);
-            }
-            GANQ_HIP_CHECK(hipEventRecord(la->rest_done, la->side));
+            GANQ_HIP_CHECK(hipEventRecord(la->panel_done, stream));
+            GANQ_HIP_CHECK(hipStreamWaitEvent(la->side, la->panel_done, 0));
+            if (nblk > 1)
+                hipLaunchKernelGGL(chol_update_kernel, dim3(nblk - 1), dim3(256), smem, la->side, A, lda, (int)n, (int)j, nb, 3);
+            GANQ_HIP_CHECK(hipEventRecord(la->col_done, la->side));
+            if (nblk > 1)
+                hipLaunchKernelGGL(chol_update_kernel, dim3((nblk - 1) * nblk / 2), dim3(256), smem, la->side, A, lda, (int)n, (int)j, nb, 2);
+            GANQ_HIP_CHECK(hipEventRecord(la->rest_done[step & 1], la->side));
         }
     }
-    if (two) GANQ_HIP_CHECK(hipStreamWaitEvent(stream, la->rest_done, 0));
+    if (two) {  // (the last steps' updates: both parities)
+        GANQ_HIP_CHECK(hipStreamWaitEvent(stream, la->rest_done[0], 0));
+        GANQ_HIP_CHECK(hipStreamWaitEvent(stream, la->rest_done[1], 0));
+        GANQ_HIP_CHECK(hipStreamWaitEvent(stream, la->col_done, 0));
+    }
     hipLaunchKernelGGL(chol_zero_upper_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, stream, A, lda, (int)n);
     GANQ_LAUNCH_CHECK();
     return 0;

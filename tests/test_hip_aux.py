@@ -208,6 +208,39 @@ def test_cholesky_vs_fp64(hip, n):
     assert rel_fro(L, ref) < 4 * max(rel_fro(Lt, ref), 1e-7)
 
 
+@pytest.mark.parametrize("n", [4096, 4230])
+def test_cholesky_lookahead_path(hip, n, lib_options):
+    """from 4096 columns on the factorisation runs its trailing updates on a second stream and the diagonal kernel applies the previous
+    step's update to its own block: against fp64, against the single-stream order (GANQ_CHOL_LOOKAHEAD=0: the same additions per
+    element in another order of the two K = 128 products -- fp32 rounding apart), twice in a row and two at once on two streams
+    (the prologue does that), a ragged last block included"""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    X = torch.randn(2 * n, n, device="cuda", generator=g) * (0.1 + torch.rand(n, device="cuda", generator=g))
+    H = (X.T @ X) / X.shape[0]
+    H += 0.01 * H.diag().mean() * torch.eye(n, device="cuda")
+    L = hip.cholesky(H)
+    assert torch.equal(hip.cholesky(H), L)
+    Hd = H.double()
+    assert float((L.double() @ L.double().T - Hd).norm() / Hd.norm()) < 2e-6
+    ref = torch.linalg.cholesky(Hd)
+    assert float((L.double() - ref).norm() / ref.norm()) < 2e-6
+    assert torch.all(torch.triu(L, 1) == 0)
+    lib_options(GANQ_CHOL_LOOKAHEAD=0)
+    L0 = hip.cholesky(H)
+    lib_options(GANQ_CHOL_LOOKAHEAD=1)
+    assert float((L - L0).abs().max() / L0.abs().max()) < 1e-5
+    H2 = H + 0.5 * torch.eye(n, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        La = hip.cholesky(H)
+    with torch.cuda.stream(s2):
+        Lb = hip.cholesky(H2)
+    torch.cuda.synchronize()
+    assert torch.equal(La, L)
+    assert float((Lb.double() @ Lb.double().T - H2.double()).norm() / H2.double().norm()) < 2e-6
+
+
 def test_cholesky_not_positive_definite_raises(hip):
     H = np.eye(200, dtype=np.float32)
     H[150, 150] = -1.0
