@@ -381,6 +381,117 @@ __device__ __forceinline__ void km_level_top16(const double* cw, const double* c
     km_lds_barrier();
 }
 
+// Bitonic sort of a row's (value, column) keys, result in keys[0 .. P) (LDS), P = the power of two >= n, padding keys = ~0.
+// Thread t holds the keys t, t + 1024, .. in REGISTERS: a pass whose partner distance j is >= 1024 exchanges inside the thread, a pass with
+// j < 64 inside the wave (two 32-bit lane permutes per key, no barrier), and only the passes with 64 <= j < 1024 -- 18 of the 78 at
+// P = 4096 -- go through LDS and the workgroup's barrier.  (Rounds 1-3 ran every pass as compare-exchanges on the LDS array: 135 k
+// cycles per row at n = 4096, 7 % of the kernel.)  The keys are distinct (the column is part of the key), so the sorted order is the
+// one and only: the same bits as before.
+template <int E>
+__device__ __forceinline__ void km_sort_regs(const float* __restrict__ wrow, int n, int P, uint64_t* keys, int tid) {
+    uint64_t key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + KL_THREADS * e;
+        uint64_t kv = ~0ull;
+        if (i < n) {
+            uint32_t b = __builtin_bit_cast(uint32_t, wrow[i]);
+            b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
+            kv = ((uint64_t)b << 32) | (uint32_t)i;
+        }
+        key[e] = kv;
+    }
+    auto keep = [](uint64_t a, uint64_t p, bool lower, bool asc) { return (lower == asc) ? (a < p ? a : p) : (a < p ? p : a); };
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= KL_THREADS) {  // inside the thread
+                const int je = j / KL_THREADS;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & je) != 0 || (e | je) >= E) continue;
+                    const int i = tid + KL_THREADS * e;
+                    const bool asc = (i & k) == 0;
+                    const uint64_t a = key[e], b = key[e | je];
+                    const bool sw = (a > b) == asc;
+                    key[e] = sw ? b : a;
+                    key[e | je] = sw ? a : b;
+                }
+            } else if (j >= 64) {   // across waves: through LDS
+#pragma unroll
+                for (int e = 0; e < E; ++e) keys[tid + KL_THREADS * e] = key[e];
+                __syncthreads();
+                uint64_t pk[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) pk[e] = keys[(tid + KL_THREADS * e) ^ j];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid + KL_THREADS * e;
+                    key[e] = keep(key[e], pk[e], (i & j) == 0, (i & k) == 0);
+                }
+            } else {                // inside the wave
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid + KL_THREADS * e;
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key[e], j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key[e] >> 32), j);
+                    key[e] = keep(key[e], ((uint64_t)hi << 32) | lo, (i & j) == 0, (i & k) == 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[tid + KL_THREADS * e] = key[e];
+    __syncthreads();
+}
+
+// the LDS version (rows shorter than the workgroup, and rows of more than 4096 keys: 8 or 16 keys per thread in registers cost the
+// windowed kernel more than the LDS passes -- n = 11008: 97.5 against 84.7 ms per 4096 rows)
+__device__ __forceinline__ void km_sort_lds(const float* __restrict__ wrow, int n, int P, uint64_t* keys, int tid) {
+    for (int i = tid; i < P; i += KL_THREADS) {
+        uint64_t key = ~0ull;
+        if (i < n) {
+            uint32_t b = __builtin_bit_cast(uint32_t, wrow[i]);
+            b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
+            key = ((uint64_t)b << 32) | (uint32_t)i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += KL_THREADS) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const bool asc = (i & k) == 0;
+                    const uint64_t a = keys[i], b = keys[partner];
+                    if ((a > b) == asc) {
+                        keys[i] = b;
+                        keys[partner] = a;
+                    }
+                }
+            }
+            // a pass with j < 64 pairs elements of the same wave (thread t holds t, t + 1024, ..): it only has to wait for
+            // that wave's own LDS traffic; the workgroup meets before the next pass that reaches across waves
+            // (a pass that reached across waves itself must also be complete for everybody before anyone goes on)
+            const int jn = j > 1 ? (j >> 1) : k;  // distance of the next pass
+            if (j >= 64 || jn >= 64 || (j == 1 && k == P)) __syncthreads();
+            else {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void km_sort_row(const float* __restrict__ wrow, int n, int P, uint64_t* keys, int tid) {
+    switch (P / KL_THREADS) {
+        case 1: km_sort_regs<1>(wrow, n, P, keys, tid); break;
+        case 2: km_sort_regs<2>(wrow, n, P, keys, tid); break;
+        case 4: km_sort_regs<4>(wrow, n, P, keys, tid); break;
+        default: km_sort_lds(wrow, n, P, keys, tid); break;
+    }
+}
+
 // MINW = waves per SIMD the register allocation must allow: 4 (one workgroup per CU) or 8 (two, when two rows' arrays
 // fit the LDS together: n <= 2.3 k)
 template <int MINW>
@@ -414,40 +525,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
         unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
         // ---- 1. sort ------------------------------------------------------------------------------
-        for (int i = tid; i < P; i += KL_THREADS) {
-            uint64_t key = ~0ull;
-            if (i < n) {
-                uint32_t b = __builtin_bit_cast(uint32_t, W[(int64_t)row * n + i]);
-                b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
-                key = ((uint64_t)b << 32) | (uint32_t)i;
-            }
-            keys[i] = key;
-        }
-        __syncthreads();
-        for (int k = 2; k <= P; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P; i += KL_THREADS) {
-                    const int partner = i ^ j;
-                    if (partner > i) {
-                        const bool asc = (i & k) == 0;
-                        const uint64_t a = keys[i], b = keys[partner];
-                        if ((a > b) == asc) {
-                            keys[i] = b;
-                            keys[partner] = a;
-                        }
-                    }
-                }
-                // a pass with j < 64 pairs elements of the same wave (thread t holds t, t + 1024, ..): it only has to wait for
-                // that wave's own LDS traffic; the workgroup meets before the next pass that reaches across waves
-                // (a pass that reached across waves itself must also be complete for everybody before anyone goes on)
-                const int jn = j > 1 ? (j >> 1) : k;  // distance of the next pass
-                if (j >= 64 || jn >= 64 || (j == 1 && k == P)) __syncthreads();
-                else {
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
+        km_sort_row(W + (int64_t)row * n, n, P, keys, tid);
         for (int u = tid; u < n; u += KL_THREADS) {
             const uint64_t key = keys[u];
             uint32_t b = (uint32_t)(key >> 32);
@@ -671,40 +749,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
 
     for (int row = blockIdx.x; row < m; row += gridDim.x) {
         // ---- 1. sort ------------------------------------------------------------------------------
-        for (int i = tid; i < P; i += KL_THREADS) {
-            uint64_t key = ~0ull;
-            if (i < n) {
-                uint32_t b = __builtin_bit_cast(uint32_t, W[(int64_t)row * n + i]);
-                b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
-                key = ((uint64_t)b << 32) | (uint32_t)i;
-            }
-            keys[i] = key;
-        }
-        __syncthreads();
-        for (int k = 2; k <= P; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P; i += KL_THREADS) {
-                    const int partner = i ^ j;
-                    if (partner > i) {
-                        const bool asc = (i & k) == 0;
-                        const uint64_t a = keys[i], b = keys[partner];
-                        if ((a > b) == asc) {
-                            keys[i] = b;
-                            keys[partner] = a;
-                        }
-                    }
-                }
-                // a pass with j < 64 pairs elements of the same wave (thread t holds t, t + 1024, ..): it only has to wait for
-                // that wave's own LDS traffic; the workgroup meets before the next pass that reaches across waves
-                // (a pass that reached across waves itself must also be complete for everybody before anyone goes on)
-                const int jn = j > 1 ? (j >> 1) : k;  // distance of the next pass
-                if (j >= 64 || jn >= 64 || (j == 1 && k == P)) __syncthreads();
-                else {
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
+        km_sort_row(W + (int64_t)row * n, n, P, keys, tid);
         for (int u = tid; u < n; u += KL_THREADS) {
             const uint64_t key = keys[u];
             uint32_t b = (uint32_t)(key >> 32);
