@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GANQ_HIP_ABI_VERSION 3
+#define GANQ_HIP_ABI_VERSION 4
 
 /* flags for ganq_run_layer */
 #define GANQ_FLAG_ALIAS_Q 1u /* reference torch-branch behaviour: indices of the LAST iteration are returned with \

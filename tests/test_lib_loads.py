@@ -27,7 +27,7 @@ def test_library_builds_loads_and_exports_everything():
     handle = _lib.lib()
     for name in declared_symbols():
         assert hasattr(handle, name), name
-    assert handle.ganq_hip_version() == 3
+    assert handle.ganq_hip_version() == 4
     # size queries are pure host functions
     # Err scratch + packed L, plus what the helper workgroups of small launches need (accumulators and their own Err copy for at
     # most 128 tiles and two helpers each, flags): 64 MiB + 64 MiB + 2 x (32.5 MiB + 32 MiB) + 5 KiB at 4096 x 4096

@@ -13,6 +13,7 @@ def timed(fn, reps=6):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 rows, seq = 16384, 2048
+_lib.debug_option("GANQ_HESS_W4", 2)  # (the product takes the transposed path from 3072 in_features on; here every size is timed)
 for n in [int(a) for a in sys.argv[1:]] or [4096, 2048, 8192, 14336, 3072, 1024]:
     xs = [(torch.randn(seq, n, device="cuda") * 0.5).half() for _ in range(rows // seq)]
     H = torch.zeros(n, n, device="cuda")

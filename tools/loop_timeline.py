@@ -3,7 +3,7 @@ the idle gap before each.  usage: loop_timeline.py kernel_trace.csv [max_rows]""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-names = [r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ganq::", "") for r in rows]
+names = [r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ganq::", "") for r in rows]
 # last launch group that starts with l_pack_kernel (one per run_layer)
 starts = [i for i, nm in enumerate(names) if nm.startswith("l_pack_kernel")]
 a = starts[-1]

@@ -20,7 +20,7 @@ if __name__ == "__main__":
     for d in dirs:
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ganq::", "")
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ganq::", "")
                 if len(name) > 60 or "ganq" not in r["Kernel_Name"]:
                     continue
                 key = r["Counter_Name"] + "_KB_avg"

@@ -6,7 +6,7 @@ src, dst = sys.argv[1], sys.argv[2]
 rows = list(csv.reader(open(src)))
 out = [rows[0]]
 for r in rows[1:]:
-    name = r[0].split("(")[0]
+    name = r[0].replace("(anonymous namespace)::", "").split("(")[0]
     if name.startswith("void "):
         name = name[5:]
     r[0] = name[:90]
