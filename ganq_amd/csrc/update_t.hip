@@ -23,6 +23,7 @@
 // The per-row 16x16 systems are then solved in fp64 (round-robin Jacobi, gelsd cut-off); with A exact and
 // b = S (W H) accumulated in fp64 the closed-form loss has no cancellation problem, so no (W-Wq)@H product is
 // needed per iteration.
+#include <climits>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1453,6 +1454,11 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
     long long* changed = stateful ? reinterpret_cast<long long*>(ws + lo.off_chgcnt + align_up((size_t)m * sizeof(int), 8)) : nullptr;
     // more than 1/16 of all indices changed: the full accumulation is cheaper (decided on the device, no host sync)
     const long long thr = opt_thr >= 0 ? opt_thr : (long long)((m * n) >> 4);
+    // From the second incremental iteration on the device-side fallback is not even launched (three launches that find the gate shut:
+    // 14 us per iteration): the changes shrink from iteration to iteration (the incremental kernel's time on the benchmark layer:
+    // 233, 135, 115, 96, 81, 60 .. us), and if a layer ever did change more than 1/16 of its indices that late, the incremental
+    // update is still exact -- just slower than the full pass would have been.  (A forced threshold, GANQ_T_INCR_THR, keeps the gate.)
+    const bool gated = !(stateful && iter >= 2 && opt_thr < 0);
     const long long* gate = nullptr;  // null: the full path runs unconditionally
     if (stateful && iter > 0) {
         ProfScope prof(KID_T_INCR, stream);
@@ -1465,7 +1471,7 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         const short* Jint = reinterpret_cast<const short*>(ws + lo.off_jint);
         if ((n & 15) == 0 && !mu_lds)
             hipLaunchKernelGGL(m_update_mfma_kernel, dim3((unsigned)m), dim3(MG_WAVES * 64), 0, stream, planes, Hint, Jint, hdiag,
-                               hdiag_j, Q, qprev, (int)m, (int)n, (int)lo.nq, chg, chgcnt, mstate, mstate_lo, changed, thr, prep);
+                               hdiag_j, Q, qprev, (int)m, (int)n, (int)lo.nq, chg, chgcnt, mstate, mstate_lo, changed, gated ? thr : LLONG_MAX, prep);
         else {
             int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(m_update_kernel<int>), usmem);
             if (!rc) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(m_update_kernel<short>), usmem);
@@ -1473,14 +1479,14 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
             // the extension word first (it needs the old codes; leaves at once when the extension is off), then the
             // 31-bit word, which also brings Qprev up to date
             hipLaunchKernelGGL(m_update_kernel<short>, dim3((unsigned)m), dim3(MU_WAVES * 64), usmem, stream, Jint, Q, qprev, (int)m,
-                               (int)n, chg, chgcnt, mstate_lo, changed, thr, prep);
+                               (int)n, chg, chgcnt, mstate_lo, changed, gated ? thr : LLONG_MAX, prep);
             hipLaunchKernelGGL(m_update_kernel<int>, dim3((unsigned)m), dim3(MU_WAVES * 64), usmem, stream, Hint, Q, qprev, (int)m,
-                               (int)n, chg, chgcnt, mstate, changed, thr, prep);
+                               (int)n, chg, chgcnt, mstate, changed, gated ? thr : LLONG_MAX, prep);
         }
         GANQ_LAUNCH_CHECK();
         gate = changed;
     }
-    {
+    if (gated) {
         ProfScope prof(KID_SORT_CODES, stream);
         const int64_t items = m * lo.ng;
         hipLaunchKernelGGL(code_masks_kernel, dim3((unsigned)std::min<int64_t>((items + 3) / 4, 4096)), dim3(256), 0, stream, Q, (int)m, (int)n,
@@ -1492,7 +1498,7 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(onehot_accum_kernel), smem);
         if (rc) return rc;
     }
-    {
+    if (gated) {
         ProfScope prof(KID_SHT_ACCUM, stream);
         const int nrg = (int)((m + TR - 1) / TR);
         const bool dbg = opt_get(OPT_ACCUM_DEBUG) == 1;  // developer timing experiment

@@ -205,7 +205,7 @@ def test_solve_s_helper_workgroups_on_concurrent_streams(hip, lib_options):
     t_seq = (time.perf_counter() - t0) / 3
     streams = [torch.cuda.Stream() for _ in data]
     t_conc = []
-    for _ in range(3):
+    for rnd in range(4):  # (round 0 is not timed: a stream's first launch allocates its workspace -- 18 ms on a cold allocator)
         outs = []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -216,7 +216,8 @@ def test_solve_s_helper_workgroups_on_concurrent_streams(hip, lib_options):
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
-        t_conc.append(time.perf_counter() - t0)
+        if rnd:
+            t_conc.append(time.perf_counter() - t0)
         for o, r in zip(outs, ref):
             assert torch.equal(o, r)
     lib_options(GANQ_SOLVE_DUO=2)  # helpers that never answer: every chain wave times out once, then works alone
