@@ -80,6 +80,7 @@ enum Opt : int {
     OPT_GEMM_H16_BM,
     OPT_LUT_DENSE_M,
     OPT_HESS_W4,
+    OPT_KMEANS_SPAN,
     OPT_COUNT
 };
 long long opt_get(int id);

@@ -54,6 +54,9 @@ __device__ __forceinline__ void km_better_asc(double& bc, int& bj, double c, int
 // tie-breaks as kmeans_kernel; only where the operands live differs -- the global-memory variant spends its time waiting
 // on one dependent L2 round trip per candidate.
 constexpr int KL_THREADS = 1024;
+#ifndef KM_SPAN_HS
+#define KM_SPAN_HS 512  // windowed kernel: from this node spacing down a layer may switch to solving its levels span by span (sweep: tools/dev/kmeans_span_sweep.py)
+#endif
 #ifndef KM_LONG
 #define KM_LONG 16  // measured on MI355X (4096x4096, V=16): 4 -> 30 ms, 8 -> 23 ms, 16 -> 19 ms, 48 -> 22 ms
 #endif
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
 template <int MINW>
 __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const float* __restrict__ W, const double* __restrict__ col_weight,
                                                                 int m, int n, int V, int P, int Wcap, float* __restrict__ T0,
-                                                                char* __restrict__ ws, size_t ws_stride) {
+                                                                char* __restrict__ ws, size_t ws_stride, int span_hs) {
     extern __shared__ __align__(16) char km_smem[];
     double* wcw = reinterpret_cast<double*>(km_smem);  // window copies, index j - base
     double* wcwx = wcw + Wcap;
@@ -867,7 +870,97 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
             };
             solve_wide(n - 1, (int)aprev[n - 1], n - 1);
             if (k == V - 1) break;  // only D[V-1][n-1] is needed from the last layer
+            // the nodes t0 .. t1 of level hs, whose candidates all lie in the staged window [base, ..)
+            auto run_nodes = [&](int hs, int t0, int t1, int base) {
+                auto node_lo = [&](int t) {
+                    const int i = hs - 1 + t * 2 * hs;
+                    return max((i - hs >= 0) ? (int)acur[i - hs] : 0, (int)aprev[i]);
+                };
+                auto node_hi = [&](int t) {
+                    const int i = hs - 1 + t * 2 * hs;
+                    const int right = (i + hs < n) ? (i + hs) : (n - 1);
+                    return max(node_lo(t), min(i, (int)acur[right]));
+                };
+                const int segcnt = t1 - t0 + 1;
+                int G = 1;
+                while (G < KL_THREADS && G * 2 * segcnt <= KL_THREADS) G <<= 1;
+                const int lg = tid & (G - 1);
+                if (G <= 64) {
+                    km_level_nodes(wcw, wcwx, wcwxx, wdp, base, cw, cwx, cwxx, acur, dcur, ag, t0, t1, hs, n, G, aprev);
+                    __syncthreads();
+                } else {
+                    const int t = t0 + tid / G;
+                    const int i = hs - 1 + t * 2 * hs;
+                    double bc = INFINITY;
+                    int bj = 0x7fffffff;
+                    if (t <= t1) {
+                        const int lo = node_lo(t), hi = node_hi(t);
+                        const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
+                        for (int j = lo + lg; j <= hi; j += G) {
+                            const int idx = j - base;
+                            km_better_asc(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
+                        }
+                    }
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const double oc = __shfl_xor(bc, off);
+                        const int oj = __shfl_xor(bj, off);
+                        km_better(bc, bj, oc, oj);
+                    }
+                    if ((tid & 63) == 0) {
+                        red_c[tid >> 6] = bc;
+                        red_j[tid >> 6] = bj;
+                    }
+                    __syncthreads();
+                    if (lg == 0 && t <= t1) {
+                        const int w0 = tid >> 6;
+                        for (int w = 1; w < G / 64; ++w) km_better(bc, bj, red_c[w0 + w], red_j[w0 + w]);
+                        dcur[i] = bc;
+                        ag[i] = bj;
+                        acur[i] = (uint16_t)bj;
+                    }
+                    __syncthreads();
+                }
+            };
+            // The upper levels: one level at a time, every level walks its nodes in segments whose candidate window
+            // fits the LDS window (the top levels' ranges are long).
+            // The lower levels (round 4): SPAN by span.  Behind a level of spacing 2 hs the positions D - 1, 2 D - 1, .. (D = 2 hs) and
+            // n - 1 are solved; every node between two of them has its candidates between THEIR argmins (monotone), so a run of
+            // consecutive intervals whose window [max(opt(left end), lower bound of the first position), opt(right end)] fits is
+            // staged ONCE and all the levels inside it are solved from that copy.  The switch happens at the first level (from
+            // spacing `span_hs` down) at which every single interval fits the window -- per layer: 256-1024 at n = 8192-14336.
+            // Rounds 1-3 staged per level: thirteen windows' worth of four arrays per layer at n = 8192 instead of five,
+            // ~600 segment set-ups per row.  Same candidates, same (cost, leftmost j) order: the same bits.
             for (int hs = P >> 1; hs >= 1; hs >>= 1) {
+                if (hs <= span_hs) {  // from the first level on whose every interval fits the window: span by span
+                    const int D = 2 * hs;
+                    const int nint = (n - 1 + D - 1) / D;  // intervals (u D - 1, min((u + 1) D - 1, n - 1)), u = 0 .. nint - 1
+                    auto span_lo = [&](int u) {            // lowest candidate of any node inside interval u
+                        const int iL = u * D - 1;
+                        return max(iL >= 0 ? (int)acur[iL] : 0, (int)aprev[iL + 1]);
+                    };
+                    auto span_hi = [&](int u) { return (int)acur[min((u + 1) * D - 1, n - 1)]; };
+                    bool fits = true;
+                    for (int u = 0; u < nint && fits; ++u) fits = span_hi(u) - span_lo(u) + 1 <= Wcap;
+                    if (fits) {
+                        int u0 = 0;
+                        while (u0 < nint) {
+                            const int base = span_lo(u0);
+                            int u1 = u0;
+                            while (u1 + 1 < nint && span_hi(u1 + 1) - base + 1 <= Wcap) ++u1;
+                            stage(base, span_hi(u1) - base + 1);
+                            __syncthreads();
+                            const int iR = min((u1 + 1) * D - 1, n - 1);
+                            for (int h = hs; h >= 1; h >>= 1) {
+                                const int cnt_h = (n - 1 > h - 1) ? ((n - 1 - (h - 1) + 2 * h - 1) / (2 * h)) : 0;
+                                const int ta = u0 * (D / (2 * h));
+                                const int tb = min(cnt_h - 1, (iR - h) / (2 * h));  // positions h - 1 + 2 h t < iR
+                                if (iR - h >= 0 && tb >= ta) run_nodes(h, ta, tb, base);
+                            }
+                            u0 = u1 + 1;
+                        }
+                        break;  // every level from hs down is done
+                    }
+                }
                 const int cnt = (n - 1 > hs - 1) ? ((n - 1 - (hs - 1) + 2 * hs - 1) / (2 * hs)) : 0;
                 auto node_lo = [&](int t) {
                     const int i = hs - 1 + t * 2 * hs;
@@ -896,47 +989,9 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
                             hi_t = mid - 1;
                         }
                     }
-                    const int segcnt = t1 - t0 + 1;
                     stage(base, node_hi(t1) - base + 1);
                     __syncthreads();
-                    int G = 1;
-                    while (G < KL_THREADS && G * 2 * segcnt <= KL_THREADS) G <<= 1;
-                    const int lg = tid & (G - 1);
-                    if (G <= 64) {
-                        km_level_nodes(wcw, wcwx, wcwxx, wdp, base, cw, cwx, cwxx, acur, dcur, ag, t0, t1, hs, n, G, aprev);
-                        __syncthreads();
-                    } else {
-                        const int t = t0 + tid / G;
-                        const int i = hs - 1 + t * 2 * hs;
-                        double bc = INFINITY;
-                        int bj = 0x7fffffff;
-                        if (t <= t1) {
-                            const int lo = node_lo(t), hi = node_hi(t);
-                            const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
-                            for (int j = lo + lg; j <= hi; j += G) {
-                                const int idx = j - base;
-                                km_better_asc(bc, bj, wdp[idx] + km_cost4(wcw[idx], wcwx[idx], wcwxx[idx], ci, cxi, cxxi), j);
-                            }
-                        }
-                        for (int off = 32; off > 0; off >>= 1) {
-                            const double oc = __shfl_xor(bc, off);
-                            const int oj = __shfl_xor(bj, off);
-                            km_better(bc, bj, oc, oj);
-                        }
-                        if ((tid & 63) == 0) {
-                            red_c[tid >> 6] = bc;
-                            red_j[tid >> 6] = bj;
-                        }
-                        __syncthreads();
-                        if (lg == 0 && t <= t1) {
-                            const int w0 = tid >> 6;
-                            for (int w = 1; w < G / 64; ++w) km_better(bc, bj, red_c[w0 + w], red_j[w0 + w]);
-                            dcur[i] = bc;
-                            ag[i] = bj;
-                            acur[i] = (uint16_t)bj;
-                        }
-                        __syncthreads();
-                    }
+                    run_nodes(hs, t0, t1, base);
                     t0 = t1 + 1;
                 }
             }
@@ -1044,6 +1099,9 @@ extern "C" int ganq_kmeans_init(const float* W, const double* col_weight, int64_
         if (rc) return rc;
     }
     ProfScope prof(KID_KMEANS, stream);
+    // (windowed kernel) levels with this spacing and below are solved span by span; GANQ_KMEANS_SPAN (developer): another power of two, 0 = never
+    int span_hs = (int)opt_get(OPT_KMEANS_SPAN);
+    if (span_hs < 0) span_hs = KM_SPAN_HS;
     if (p.lds && p.per_cu >= 2)
         hipLaunchKernelGGL(kmeans_lds_kernel<8>, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n, V,
                            p.P, p.qcap, T0, static_cast<char*>(workspace), p.stride);
@@ -1053,10 +1111,10 @@ extern "C" int ganq_kmeans_init(const float* W, const double* col_weight, int64_
     else
         if (p.per_cu >= 2)
             hipLaunchKernelGGL(kmeans_win_kernel<8>, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n,
-                               V, p.P, p.Wcap, T0, static_cast<char*>(workspace), p.stride);
+                               V, p.P, p.Wcap, T0, static_cast<char*>(workspace), p.stride, span_hs);
         else
             hipLaunchKernelGGL(kmeans_win_kernel<4>, dim3(p.grid), dim3(KL_THREADS), p.smem, stream, W, col_weight, (int)m, (int)n,
-                               V, p.P, p.Wcap, T0, static_cast<char*>(workspace), p.stride);
+                               V, p.P, p.Wcap, T0, static_cast<char*>(workspace), p.stride, span_hs);
     GANQ_LAUNCH_CHECK();
     return 0;
 }

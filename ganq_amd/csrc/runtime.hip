@@ -60,6 +60,7 @@ const OptDesc kOpts[OPT_COUNT] = {
     {"GANQ_GEMM_H16_BM", 0},       // dense GEMM of the LUT forward: force 128- / 256-row tiles (0: by tile count)
     {"GANQ_LUT_DENSE_M", -1},      // LUT forward: from this many rows of x on, dequantise once + dense GEMM (-1: by shape; 0: never)
     {"GANQ_HESS_W4", 1},           // Hessian, staged groups: 0 = never the transposed staging + 256 x 256 stream-K kernel (hessian_w4.hip); 2 = from 1024 in_features on (default: 3072)
+    {"GANQ_KMEANS_SPAN", -1},      // windowed k-means: node spacing from which the levels are solved span by span (-1: default; 0: level by level as in rounds 1-3)
 };
 
 std::atomic<long long> g_opt[OPT_COUNT];
