@@ -36,6 +36,7 @@ SIGNATURES = {
     "ganq_debug_gemm_h16": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp]),
     "ganq_hessian_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "ganq_hessian_accum": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_vp, _c_sz, _c_vp]),
+    "ganq_debug_hessian_t_cut": (ctypes.c_int, [_c_i64, _c_i64, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int, _c_vp, ctypes.c_int]),
     "ganq_hessian_t_supported": (ctypes.c_int, [_c_i64, _c_i64]),
     "ganq_hessian_t_workspace_bytes": (_c_sz, [_c_i64]),
     "ganq_hessian_stage_t": (ctypes.c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),

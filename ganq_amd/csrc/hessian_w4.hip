@@ -84,15 +84,99 @@ __global__ __launch_bounds__(256) void hw_stage_kernel(const uint16_t* __restric
         }
 }
 
+// ---- the cut of a launch (shared by the host, the kernels and the CPU test of the cut: tests/test_host_logic.py through
+// ganq_debug_hessian_t_cut).  T tiles of Ks token slices on G workgroups: W = T div G whole tiles per workgroup first (tile w G + c:
+// everybody walks the tokens of a row of tiles in step, the operand panels are shared in the L2).  The R = T mod G tiles left over are
+// cut so that the workgroups still read the same tokens at the same time: workgroup c < nprim is the PRIMARY of left-over tile c and
+// takes its slices [0, P); the others are HELPERS that share the tails [P, Ks) of all left-over tiles in equal contiguous ranges of Sh
+// slices, each started at the tile boundary inside its range (primaries are at slice tau, helpers at P + tau or P + tau - (Sh - Lt) at any
+// time tau; a plain linear cut of the (tile, slice) pairs spreads the workgroups over all token offsets, every panel is then fetched
+// past the L2 by each of them: 294 us of slice loops at n = 4096 instead of 190).  nprim = 0, P = 0 is the plain linear cut of the
+// left-over tiles (taken when a helper range would touch more than three tiles: Sh > 2 (Ks - P)).
+struct HwCut { int Ks, G, W, R, nprim, P, Sh; };
+struct HwSeg { int t, s0, s1, np, slot; };  // slices [s0, s1) of tile t: one of the tile's np parts, kept in slot `slot` of the workgroup's partial tiles when np > 1
+
+inline HwCut hw_make_cut(int64_t T, int64_t Ks, int G) {
+    HwCut q{(int)Ks, G, (int)(T / G), (int)(T % G), 0, 0, 1};
+    if (q.R > 0) {
+        q.P = (int)(((int64_t)q.R * Ks + G - 1) / G);
+        const int64_t Lt = Ks - q.P;
+        const int64_t sh = G > q.R && Lt > 0 ? ((int64_t)q.R * Lt + (G - q.R) - 1) / (G - q.R) : 0;
+        if (q.P < Ks && sh >= 1 && sh <= 2 * Lt) {
+            q.nprim = q.R;
+            q.Sh = (int)sh;
+        } else {  // the plain linear cut of the left-over tiles
+            q.P = 0;
+            q.Sh = (int)std::max<int64_t>(1, ((int64_t)q.R * Ks + G - 1) / G);
+        }
+    }
+    return q;
+}
+
+// helpers whose ranges touch left-over tile r: the first one's number -> hf, their count returned
+__host__ __device__ inline int hw_helpers_of(const HwCut& q, int r, int& hf) {
+    const int Lt = q.Ks - q.P;
+    hf = (int)(((long long)r * Lt) / q.Sh);
+    return (int)((((long long)(r + 1)) * Lt - 1) / q.Sh) - hf + 1;
+}
+
+// parts of left-over tile r, in the order they are summed: the primary's (when P > 0), then the helpers' along the tail
+__host__ __device__ inline int hw_parts_of(const HwCut& q, int r) {
+    int hf;
+    return (q.P > 0 ? 1 : 0) + hw_helpers_of(q, r, hf);
+}
+__host__ __device__ inline void hw_part_location(const HwCut& q, int r, int pi, int& wg, int& slot) {
+    const int pb = q.P > 0 ? 1 : 0;
+    wg = r;
+    slot = 0;
+    if (pi >= pb) {
+        int hf;
+        (void)hw_helpers_of(q, r, hf);
+        const int h = hf + pi - pb, Lt = q.Ks - q.P;
+        wg = q.nprim + h;
+        slot = r - (int)(((long long)h * q.Sh) / Lt);
+    }
+}
+
+// the left-over segments of workgroup c (at most three), in the order it works through them -> count
+__host__ __device__ inline int hw_left_segments(const HwCut& q, int c, HwSeg (&left)[3]) {
+    int nleft = 0;
+    if (q.R <= 0) return 0;
+    const int Lt = q.Ks - q.P, t0 = q.W * q.G;
+    if (c < q.nprim) {
+        left[nleft++] = HwSeg{t0 + c, 0, q.P, hw_parts_of(q, c), 0};
+        return nleft;
+    }
+    const int h = c - q.nprim;
+    const long long a = (long long)h * q.Sh, tot = (long long)q.R * Lt;
+    const long long b = a + q.Sh < tot ? a + q.Sh : tot;
+    if (a >= b) return 0;
+    const int r0 = (int)(a / Lt);
+    long long x = (a % Lt == 0) ? a : (long long)(r0 + 1) * Lt;  // the tile boundary inside the range: the helper starts there
+    if (x >= b) x = a;
+    for (int pass = 0; pass < 2; ++pass) {
+        long long pos = pass == 0 ? x : a;
+        const long long hi = pass == 0 ? b : x;
+        while (pos < hi && nleft < 3) {
+            const int r = (int)(pos / Lt), off = (int)(pos - (long long)r * Lt);
+            const int len = (int)((long long)(Lt - off) < hi - pos ? (long long)(Lt - off) : hi - pos);
+            left[nleft++] = HwSeg{t0 + r, q.P + off, q.P + off + len, hw_parts_of(q, r), r - r0};
+            pos += len;
+        }
+    }
+    return nleft;
+}
+
 #ifdef HW_PROBE
 __device__ unsigned long long hw_probe_buf[8];
 __device__ unsigned long long hw_probe_all[1024 * 4];  // per workgroup: kernel start, loop ticks, end ticks, finish (100 MHz)  // developer (-DHW_PROBE): workgroup 0 -- cycles in the slice loops, slices, cycles in the segment ends
 #endif
 template <bool BF16>
 __global__ __launch_bounds__(256, 1) void hessian_w4_kernel(float* __restrict__ H, const uint16_t* __restrict__ Xt, int ldt, int n, float decay,
-                                                           float scale, int Ks, int nwg, int W, int R, int nprim, int P, int Sh,
+                                                           float scale, const HwCut cut,
                                                            float* __restrict__ partial, const uint32_t* __restrict__ table) {
     extern __shared__ __align__(1024) char hw_smem[];
+    const int Ks = cut.Ks, nwg = cut.G, W = cut.W;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 1, wc = wv & 1;
@@ -120,8 +204,7 @@ __global__ __launch_bounds__(256, 1) void hessian_w4_kernel(float* __restrict__ 
 
     // One segment: the token slices [s0, s1) of tile t; one of the tile's `np` parts, kept in slot `slot` of this workgroup's partial
     // tiles when np > 1.
-    struct Seg { int t, s0, s1, np, slot; };
-    auto process = [&](const Seg sg) {
+    auto process = [&](const HwSeg sg) {
         // (uniform by construction; said so explicitly: the scalar pointer arithmetic below must stay in scalar registers)
         const int t = __builtin_amdgcn_readfirstlane(sg.t), s0 = __builtin_amdgcn_readfirstlane(sg.s0), s1 = __builtin_amdgcn_readfirstlane(sg.s1);
         const int np = __builtin_amdgcn_readfirstlane(sg.np), slot = __builtin_amdgcn_readfirstlane(sg.slot);
@@ -282,50 +365,12 @@ __global__ __launch_bounds__(256, 1) void hessian_w4_kernel(float* __restrict__ 
         }
     };
 
-    // ---- this workgroup's segments.  W whole tiles per workgroup first (tile w nwg + c: everybody walks the tokens of a row of tiles
-    // in step, the operand panels are shared in the L2).  The R < nwg tiles left over are cut so that the workgroups still read the
-    // same tokens at the same time: workgroup c < nprim is the PRIMARY of left-over tile c and takes its slices [0, P); the others are
-    // HELPERS that share the tails [P, Ks) of all left-over tiles in equal contiguous ranges of Sh slices, each starting at the tile
-    // boundary inside its range (primaries are at slice tau, helpers at P + tau or P + tau - (Sh - Lt) at any time tau; a plain
-    // linear cut of the (tile, slice) pairs spreads the workgroups over all token offsets, every panel is then fetched past the L2 by
-    // each of them: 294 us of slice loops at n = 4096 instead of 190).  nprim = 0, P = 0: the plain linear cut (Sh > 2 (Ks - P)).
-    Seg left[3];
-    int nleft = 0;
-    if (R > 0) {
-        const int Lt = Ks - P, t0 = W * nwg, pb = P > 0 ? 1 : 0;
-        auto helpers_of = [&](int r, int& hf) {
-            hf = (int)(((long long)r * Lt) / Sh);
-            return (int)((((long long)(r + 1)) * Lt - 1) / Sh) - hf + 1;
-        };
-        if (c < nprim) {
-            int hf;
-            left[nleft++] = Seg{t0 + c, 0, P, 1 + helpers_of(c, hf), 0};
-        } else {
-            const int h = c - nprim;
-            const long long a = (long long)h * Sh, tot = (long long)R * Lt;
-            const long long b = a + Sh < tot ? a + Sh : tot;
-            if (a < b) {
-                const int r0 = (int)(a / Lt);
-                long long x = (a % Lt == 0) ? a : (long long)(r0 + 1) * Lt;
-                if (x >= b) x = a;
-                for (int pass = 0; pass < 2; ++pass) {
-                    long long pos = pass == 0 ? x : a;
-                    const long long hi = pass == 0 ? b : x;
-                    while (pos < hi && nleft < 3) {
-                        const int r = (int)(pos / Lt), off = (int)(pos - (long long)r * Lt);
-                        const int len = (int)((long long)(Lt - off) < hi - pos ? (long long)(Lt - off) : hi - pos);
-                        int hf;
-                        const int nh = helpers_of(r, hf);
-                        left[nleft++] = Seg{t0 + r, P + off, P + off + len, pb + nh, r - r0};
-                        pos += len;
-                    }
-                }
-            }
-        }
-    }
+    // ---- this workgroup's segments: its whole tiles, then its share of the left-over ones (hw_left_segments)
+    HwSeg left[3];
+    const int nleft = hw_left_segments(cut, c, left);
     for (int k = 0; k < W + nleft; ++k) {
         const int kl = k - W;
-        const Seg sg = k < W ? Seg{k * nwg + c, 0, Ks, 1, 0} : (kl == 0 ? left[0] : (kl == 1 ? left[1] : left[2]));
+        const HwSeg sg = k < W ? HwSeg{k * nwg + c, 0, Ks, 1, 0} : (kl == 0 ? left[0] : (kl == 1 ? left[1] : left[2]));
         process(sg);
     }
 }
@@ -334,17 +379,15 @@ __global__ __launch_bounds__(256, 1) void hessian_w4_kernel(float* __restrict__ 
 // scale * sum on the tile and its mirror image.  One workgroup per QUARTER of a tile (the 128 x 128 block one wave of the main kernel
 // held, 64 KB per part, register order: whole 1 KB lines per load instruction).  No atomics, no tickets: the kernel boundary is the
 // hand-over, the order is fixed, the result the same from run to run.
-__global__ __launch_bounds__(256) void hessian_w4_fix_kernel(float* __restrict__ H, int n, float decay, float scale, int Ks, int nwg, int W, int R,
-                                                            int nprim, int P, int Sh, const float* __restrict__ partial, const uint32_t* __restrict__ table) {
+__global__ __launch_bounds__(256) void hessian_w4_fix_kernel(float* __restrict__ H, int n, float decay, float scale, const HwCut cut,
+                                                            const float* __restrict__ partial, const uint32_t* __restrict__ table) {
     const int tid = threadIdx.x;
     const int r = (int)blockIdx.x >> 2, wvq = (int)blockIdx.x & 3;  // left-over tile, quarter (wr, wc)
-    const int t = W * nwg + r;
+    const int t = cut.W * cut.G + r;
     int bu, bv;
     hw_tile_of(table, t, bu, bv);
     const int wr = wvq >> 1, wc = wvq & 1;
-    const int Lt = Ks - P, pb = P > 0 ? 1 : 0;
-    const int hf = (int)(((long long)r * Lt) / Sh);
-    const int np = pb + (int)((((long long)(r + 1)) * Lt - 1) / Sh) - hf + 1;
+    const int np = hw_parts_of(cut, r);
     const bool diag = bu == bv;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -357,12 +400,8 @@ __global__ __launch_bounds__(256) void hessian_w4_fix_kernel(float* __restrict__
             for (int d = 0; d < 3; ++d) {
                 const int pi = pi0 + d;
                 if (pi >= np) continue;
-                int cc = r, sl = 0;
-                if (pi >= pb) {
-                    const int h = hf + pi - pb;
-                    cc = nprim + h;
-                    sl = r - (int)(((long long)h * Sh) / Lt);
-                }
+                int cc, sl;
+                hw_part_location(cut, r, pi, cc, sl);
                 const float* src = partial + ((size_t)cc * W_SLOTS + sl) * W_PART + (size_t)wvq * (W_PART / 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[d][e] = *reinterpret_cast<const hg_f32x4*>(src + (size_t)((half * 8 + e) * 256 + tid) * 4);
@@ -438,23 +477,8 @@ int hessian_w4(float* H, const void* Xt, int64_t ldt, int dtype, int64_t rows, i
     const int64_t nt = (n + WT - 1) / WT;
     const int64_t T = nt * (nt + 1) / 2;
     const int64_t Ks = rows / WSK;
-    // the cut (see the kernel): W whole tiles per workgroup, R left over
-    const int G = ncu;
-    const int W = (int)(T / G), R = (int)(T % G);
-    int nprim = 0, P = 0, Sh = 1;
-    if (R > 0) {
-        P = (int)(((int64_t)R * Ks + G - 1) / G);
-        const int64_t Lt = Ks - P;
-        const int64_t sh = G > R && Lt > 0 ? ((int64_t)R * Lt + (G - R) - 1) / (G - R) : 0;
-        if (P < Ks && sh >= 1 && sh <= 2 * Lt) {
-            nprim = R;
-            Sh = (int)sh;
-        } else {  // the plain linear cut of the left-over tiles
-            P = 0;
-            Sh = (int)std::max<int64_t>(1, ((int64_t)R * Ks + G - 1) / G);
-        }
-    }
-    const int nwg = G;
+    const HwCut cut = hw_make_cut(T, Ks, ncu);
+    const int nwg = cut.G, R = cut.R;
     int tcount = 0;
     const uint32_t* table = hessian_tile_table((int)nt, &tcount);
     if (!table || tcount != (int)T) return fail(-100, "ganq_hessian_accum_t: could not build the tile table");
@@ -464,22 +488,58 @@ int hessian_w4(float* H, const void* Xt, int64_t ldt, int dtype, int64_t rows, i
     if (dtype == 1) {
         const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(hessian_w4_kernel<true>), lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(hessian_w4_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, stream, H, Xp, (int)ldt, (int)n, decay, scale, (int)Ks,
-                           nwg, W, R, nprim, P, Sh, partial, table);
+        hipLaunchKernelGGL(hessian_w4_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, stream, H, Xp, (int)ldt, (int)n, decay, scale, cut, partial, table);
     } else {
         const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(hessian_w4_kernel<false>), lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(hessian_w4_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, stream, H, Xp, (int)ldt, (int)n, decay, scale, (int)Ks,
-                           nwg, W, R, nprim, P, Sh, partial, table);
+        hipLaunchKernelGGL(hessian_w4_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, stream, H, Xp, (int)ldt, (int)n, decay, scale, cut, partial, table);
     }
     if (R > 0)
-        hipLaunchKernelGGL(hessian_w4_fix_kernel, dim3((unsigned)(4 * R)), dim3(256), 0, stream, H, (int)n, decay, scale, (int)Ks, nwg, W, R, nprim, P, Sh,
-                           partial, table);
+        hipLaunchKernelGGL(hessian_w4_fix_kernel, dim3((unsigned)(4 * R)), dim3(256), 0, stream, H, (int)n, decay, scale, cut, partial, table);
     GANQ_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace ganq
+
+/* tests (no GPU needed): the cut of ganq_hessian_accum_t for in_features n, `rows` tokens on `ncu` workgroups, by the code the kernels
+ * run.  hdr[7] = {Ks, G, W, R, nprim, P, Sh}; segs = [ncu][W + 3][5] ints {tile, s0, s1, parts, slot}, unused entries tile = -1;
+ * parts_loc = [R][max_parts][2] ints {workgroup, slot} of every left-over tile's parts in the order they are summed (-1 padded). */
+extern "C" int ganq_debug_hessian_t_cut(int64_t n, int64_t rows, int ncu, int* hdr, int* segs, int segs_cap, int* parts_loc, int max_parts) {
+    using namespace ganq;
+    if (n <= 0 || rows <= 0 || (rows % WSK) != 0 || ncu <= 0 || !hdr) return fail(-1, "ganq_debug_hessian_t_cut: bad arguments");
+    const int64_t nt = (n + WT - 1) / WT;
+    const HwCut q = hw_make_cut(nt * (nt + 1) / 2, rows / WSK, ncu);
+    const int h[7] = {q.Ks, q.G, q.W, q.R, q.nprim, q.P, q.Sh};
+    for (int i = 0; i < 7; ++i) hdr[i] = h[i];
+    const int per = q.W + 3;
+    if (segs) {
+        if (segs_cap < ncu * per * 5) return fail(-4, "ganq_debug_hessian_t_cut: segs too small");
+        for (int c = 0; c < ncu; ++c) {
+            HwSeg left[3];
+            const int nl = hw_left_segments(q, c, left);
+            for (int k = 0; k < per; ++k) {
+                HwSeg sg{-1, 0, 0, 0, 0};
+                if (k < q.W) sg = HwSeg{k * q.G + c, 0, q.Ks, 1, 0};
+                else if (k - q.W < nl) sg = left[k - q.W];
+                int* o = segs + ((size_t)c * per + k) * 5;
+                o[0] = sg.t; o[1] = sg.s0; o[2] = sg.s1; o[3] = sg.np; o[4] = sg.slot;
+            }
+        }
+    }
+    if (parts_loc) {
+        for (int r = 0; r < q.R; ++r) {
+            const int np = hw_parts_of(q, r);
+            for (int pi = 0; pi < max_parts; ++pi) {
+                int wg = -1, sl = -1;
+                if (pi < np) hw_part_location(q, r, pi, wg, sl);
+                parts_loc[((size_t)r * max_parts + pi) * 2] = wg;
+                parts_loc[((size_t)r * max_parts + pi) * 2 + 1] = sl;
+            }
+        }
+    }
+    return 0;
+}
 
 #ifdef HW_PROBE
 extern "C" int ganq_debug_hess_w4_probe_all(unsigned long long* out) {

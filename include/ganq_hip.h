@@ -88,6 +88,10 @@ size_t ganq_hessian_t_workspace_bytes(int64_t n);
 int ganq_hessian_stage_t(void* Xt, int64_t ldt, const void* X, int64_t rows, int64_t n, int64_t tok0, void* stream);
 int ganq_hessian_accum_t(float* H, const void* Xt, int64_t ldt, int dtype, int64_t rows, int64_t n, int64_t nsamples_before,
                          int64_t batch, void* workspace, size_t workspace_bytes, void* stream);
+/* tests (host only, no GPU): how ganq_hessian_accum_t cuts its (tile, token slice) pairs over `ncu` workgroups, computed by
+ * the code the kernels run.  hdr[7] = {Ks, G, W, R, nprim, P, Sh}; segs [ncu][W + 3][5] = {tile, s0, s1, parts, slot}
+ * (tile -1: unused); parts_loc [R][max_parts][2] = {workgroup, slot} of a left-over tile's parts in summation order. */
+int ganq_debug_hessian_t_cut(int64_t n, int64_t rows, int ncu, int* hdr, int* segs, int segs_cap, int* parts_loc, int max_parts);
 
 /* ---- a2: prologue (gptq.py:280-309) -- lower Cholesky factor A = L L^T in fp32, in place (row-major, leading
  * dimension lda; the strictly upper triangle is zeroed like torch.linalg.cholesky does).  *info (device int32) is 0

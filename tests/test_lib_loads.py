@@ -3,6 +3,7 @@ symbol include/ganq_hip.h declares (no compute calls without a GPU)."""
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,3 +63,58 @@ def test_product_does_not_import_oracle():
                 src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
                 src = re.sub(r"//[^\n]*", "", src)
                 assert "ganq_oracle" not in src and "oracle/" not in src, f
+
+
+@pytest.mark.parametrize("ncu", [8, 31, 64, 104, 256, 304])
+def test_hessian_stream_k_cut_covers_every_slice_once(ncu):
+    """The cut of ganq_hessian_accum_t (hessian_w4.hip), enumerated on the host BY THE CODE THE KERNELS RUN (ganq_debug_hessian_t_cut;
+    no GPU): for every layer width / group length / workgroup count -- CU counts of other parts and partition modes included --
+    each (tile, token slice) pair belongs to exactly one segment, a workgroup leaves at most three partial tiles in distinct slots,
+    every segment of a tile reports the same part count, and the fix kernel's (workgroup, slot) list of a tile's parts names exactly
+    the segments of that tile, in the order of the token slices."""
+    import ctypes
+
+    from ganq_amd import _lib
+
+    h = _lib.lib()
+    for n in (1024, 1288, 2048, 3072, 4096, 5120, 6144, 8192, 11008, 14336):
+        for rows in (32, 64, 2048, 4128 // 32 * 32, 16384):
+            nt = (n + 255) // 256
+            T, Ks = nt * (nt + 1) // 2, rows // 32
+            hdr = (ctypes.c_int * 7)()
+            assert h.ganq_debug_hessian_t_cut(n, rows, ncu, hdr, None, 0, None, 0) == 0
+            _ks, G, W, R, nprim, P, Sh = list(hdr)
+            assert (_ks, G, W, R) == (Ks, ncu, T // ncu, T % ncu)
+            per, maxp = W + 3, 64
+            segs = (ctypes.c_int * (ncu * per * 5))()
+            loc = (ctypes.c_int * (max(R, 1) * maxp * 2))()
+            assert h.ganq_debug_hessian_t_cut(n, rows, ncu, hdr, segs, len(segs), loc, maxp) == 0
+            S = np.frombuffer(segs, dtype=np.int32).reshape(ncu, per, 5)
+            L = np.frombuffer(loc, dtype=np.int32).reshape(max(R, 1), maxp, 2)
+            cover = np.zeros((T, Ks), dtype=np.int32)
+            by_tile = {}
+            for c in range(ncu):
+                slots = []
+                for t, s0, s1, np_, slot in S[c]:
+                    if t < 0:
+                        continue
+                    assert 0 <= t < T and 0 <= s0 < s1 <= Ks, (n, rows, c, t, s0, s1)
+                    cover[t, s0:s1] += 1
+                    by_tile.setdefault(int(t), []).append((int(s0), int(s1), c, int(slot), int(np_)))
+                    if np_ > 1:
+                        assert 0 <= slot < 3
+                        slots.append(int(slot))
+                    else:
+                        assert (s0, s1) == (0, Ks)  # a lone part is a whole tile (finished from the registers)
+                assert len(slots) == len(set(slots)), (n, rows, c, slots)
+            assert (cover == 1).all(), (n, rows, ncu, np.argwhere(cover != 1)[:4])
+            for t, parts in by_tile.items():
+                parts.sort()
+                assert all(p[4] == len(parts) for p in parts), (n, rows, t, parts)
+                if len(parts) > 1:
+                    r = t - W * ncu
+                    assert 0 <= r < R and len(parts) <= maxp
+                    want = [(c, slot) for _, _, c, slot, _ in parts]
+                    got = [tuple(int(v) for v in L[r, i]) for i in range(len(parts))]
+                    assert got == want, (n, rows, t, got, want)
+                    assert tuple(L[r, len(parts)]) == (-1, -1) if len(parts) < maxp else True
