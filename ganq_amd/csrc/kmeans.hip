@@ -90,7 +90,7 @@ __device__ __forceinline__ double km_cost4(double cwj, double cwxj, double cwxxj
 // order-independent, so who scans what does not change the result.
 __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* wcwx, const double* wcwxx, const double* wdp,
                                                int base, const double* icw, const double* icwx, const double* icwxx,
-                                               uint16_t* acur, double* dcur, int* ag, int t0, int t1, int hs, int n, int G,
+                                               uint16_t* acur, double* dcur, uint16_t* ag, int t0, int t1, int hs, int n, int G,
                                                const uint16_t* aprev = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int lg = tid & (G - 1);
@@ -123,7 +123,7 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
         }
         if (valid && !is_long && lg == 0) {
             dcur[i] = bc;
-            ag[i] = bj;
+            ag[i] = (uint16_t)bj;
             acur[i] = (uint16_t)bj;
         }
         uint64_t todo = __ballot(is_long && lg == 0);
@@ -146,7 +146,7 @@ __device__ __forceinline__ void km_level_nodes(const double* wcw, const double* 
             }
             if (lane == 0) {
                 dcur[li] = c2;
-                ag[li] = j2;
+                ag[li] = (uint16_t)j2;
                 acur[li] = (uint16_t)j2;
             }
         }
@@ -213,7 +213,7 @@ __device__ __forceinline__ KmQueue km_queue_at(char* base, int cap) {
 // lose: more ranges end up in the queue pass (defaults stay at 12 everywhere).
 template <int CAP>
 __device__ __forceinline__ void km_level_balanced(const double* cw, const double* cwx, const double* cwxx, const double* dprev,
-                                                  uint16_t* acur, double* dcur, int* ag, int cnt, int hs, int n, const KmQueue& q,
+                                                  uint16_t* acur, double* dcur, uint16_t* ag, int cnt, int hs, int n, const KmQueue& q,
                                                   const uint16_t* aprev) {
     const int tid = threadIdx.x;
     for (int t = tid; t < cnt; t += KL_THREADS) {
@@ -254,7 +254,7 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
         }
         if (!queued) {
             dcur[i] = bc;
-            ag[i] = bj;
+            ag[i] = (uint16_t)bj;
             acur[i] = (uint16_t)bj;
         }
     }
@@ -280,7 +280,7 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
         if (l32 == 0) {
             km_better(bc, bj, __longlong_as_double((long long)q.seedc[e]), (int)q.seedj[e]);  // own candidates lie left: they win ties
             dcur[i] = bc;
-            ag[i] = bj;
+            ag[i] = (uint16_t)bj;
             acur[i] = (uint16_t)bj;
         }
     }
@@ -301,7 +301,7 @@ __device__ __forceinline__ void km_level_balanced(const double* cw, const double
 #define KM_R4_MIN (MINW == 8 ? 4 : 64)
 #endif
 __device__ __forceinline__ void km_level_r4(const double* cw, const double* cwx, const double* cwxx, const double* dprev, uint16_t* acur,
-                                            double* dcur, int* ag, int S, int n, double* red_c, int* red_j, const uint16_t* aprev) {
+                                            double* dcur, uint16_t* ag, int S, int n, double* red_c, int* red_j, const uint16_t* aprev) {
     const int tid = threadIdx.x;
     const int T = (n - 1) / S;        // positions i = S - 1 + t S < n - 1
     const int cntU = T - T / 4;       // ... that are not solved yet
@@ -344,7 +344,7 @@ __device__ __forceinline__ void km_level_r4(const double* cw, const double* cwx,
         }
         if (lg == 0 && valid) {
             dcur[i] = bc;
-            ag[i] = bj;
+            ag[i] = (uint16_t)bj;
             acur[i] = (uint16_t)bj;
         }
         km_lds_barrier();
@@ -358,7 +358,7 @@ __device__ __forceinline__ void km_level_r4(const double* cw, const double* cwx,
 #define KM_TOP16 1
 #endif
 __device__ __forceinline__ void km_level_top16(const double* cw, const double* cwx, const double* cwxx, const double* dprev, uint16_t* acur,
-                                               const uint16_t* aprev, double* dcur, int* ag, int S, int n) {
+                                               const uint16_t* aprev, double* dcur, uint16_t* ag, int S, int n) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = (n - 1) / S;  // positions i = S - 1 + t S < n - 1 (at most 15: one wave each)
     if (wv < T) {
@@ -377,7 +377,7 @@ __device__ __forceinline__ void km_level_top16(const double* cw, const double* c
         }
         if (lane == 0) {
             dcur[i] = bc;
-            ag[i] = bj;
+            ag[i] = (uint16_t)bj;
             acur[i] = (uint16_t)bj;
         }
     }
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
     double* xs = reinterpret_cast<double*>(my);  // [n] sorted values
     double* wts = xs + n;                        // [n] their weights
     double* dcur = wts + n;                      // [n] D[k] of the layer being solved
-    int* arg = reinterpret_cast<int*>(dcur + n); // [V][n]
+    uint16_t* arg = reinterpret_cast<uint16_t*>(dcur + n);  // [V][n] argmins for the backtrack (16 bits: n <= 16384; int32 until round 4 -- half the bytes the kernel writes)
     const int nchunk = (n + KM_CHUNK - 1) / KM_CHUNK;
 
     for (int row = blockIdx.x; row < m; row += gridDim.x) {
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
             for (int j = tid; j <= n; j += KL_THREADS) dprev[j] = (j == 0) ? 0.0 : dcur[j - 1];
             km_lds_barrier();
             KM_STAMP(2);
-            int* ag = arg + (size_t)k * n;
+            uint16_t* ag = arg + (size_t)k * n;
             {   // position n-1: full scan by the whole workgroup
                 const int i = n - 1;
                 const double ci = cw[i + 1], cxi = cwx[i + 1], cxxi = cwxx[i + 1];
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                 if (tid == 0) {
                     for (int w = 1; w < KL_THREADS / 64; ++w) km_better(bc, bj, red_c[w], red_j[w]);
                     dcur[i] = bc;
-                    ag[i] = bj;
+                    ag[i] = (uint16_t)bj;
                     acur[i] = (uint16_t)bj;
                 }
                 km_lds_barrier();
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_lds_kernel(const floa
                         const int w0 = tid >> 6;
                         for (int w = 1; w < G / 64; ++w) km_better(bc, bj, red_c[w0 + w], red_j[w0 + w]);
                         dcur[i] = bc;
-                        ag[i] = bj;
+                        ag[i] = (uint16_t)bj;
                         acur[i] = (uint16_t)bj;
                     }
                     km_lds_barrier();
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
     double* cwxx = cwx + n1;
     double* dbuf0 = cwxx + n1;                   // [n] D of even layers
     double* dbuf1 = dbuf0 + n;                   // [n] D of odd layers
-    int* arg = reinterpret_cast<int*>(dbuf1 + n);  // [V][n]
+    uint16_t* arg = reinterpret_cast<uint16_t*>(dbuf1 + n);  // [V][n]
     const int nchunk = (n + KM_CHUNK - 1) / KM_CHUNK;
 
     for (int row = blockIdx.x; row < m; row += gridDim.x) {
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
             }
             const double* dprev_g = (k & 1) ? dbuf0 : dbuf1;  // D[k-1]
             double* dcur = (k & 1) ? dbuf1 : dbuf0;
-            int* ag = arg + (size_t)k * n;
+            uint16_t* ag = arg + (size_t)k * n;
             auto stage = [&](int base, int len) {  // window := [base, base+len)
                 for (int idx = tid; idx < len; idx += KL_THREADS) {
                     const int j = base + idx;
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
                 if (tid == 0) {
                     for (int w = 1; w < KL_THREADS / 64; ++w) km_better(bc, bj, red_c[w], red_j[w]);
                     dcur[i] = bc;
-                    ag[i] = bj;
+                    ag[i] = (uint16_t)bj;
                     acur[i] = (uint16_t)bj;
                 }
                 __syncthreads();
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(KL_THREADS, MINW) void kmeans_win_kernel(const floa
                         const int w0 = tid >> 6;
                         for (int w = 1; w < G / 64; ++w) km_better(bc, bj, red_c[w0 + w], red_j[w0 + w]);
                         dcur[i] = bc;
-                        ag[i] = bj;
+                        ag[i] = (uint16_t)bj;
                         acur[i] = (uint16_t)bj;
                     }
                     __syncthreads();
@@ -1046,7 +1046,7 @@ static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (KM_LDS_BUDGET + 1024) / (lds_bytes + 1024)));
         p.per_cu = per_cu;
         p.grid = (int)std::min<int64_t>(m, 256 * per_cu);
-        p.stride = align_up(3 * (size_t)n * sizeof(double) + (size_t)V * (size_t)n * sizeof(int), 256);
+        p.stride = align_up(3 * (size_t)n * sizeof(double) + (size_t)V * (size_t)n * sizeof(uint16_t), 256);
     } else {
         p.Wcap = (int)((KM_LDS_BUDGET - acur_bytes) / (4 * sizeof(double))) & ~63;
         // two workgroups per CU with half the window each, as long as the sort keys of a row (8 B x P) fit half the
@@ -1060,7 +1060,7 @@ static KmPlan kmeans_plan(int64_t m, int64_t n, int V) {
         if (forced > 0) p.Wcap = std::min(p.Wcap, forced);
         p.smem = std::max((size_t)p.P * sizeof(uint64_t), 4 * (size_t)p.Wcap * sizeof(double) + acur_bytes);
         p.grid = (int)std::min<int64_t>(m, 256 * p.per_cu);
-        p.stride = align_up((4 * (size_t)n + 3 * (size_t)(n + 1)) * sizeof(double) + (size_t)V * (size_t)n * sizeof(int), 256);
+        p.stride = align_up((4 * (size_t)n + 3 * (size_t)(n + 1)) * sizeof(double) + (size_t)V * (size_t)n * sizeof(uint16_t), 256);
     }
     return p;
 }
