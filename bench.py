@@ -471,8 +471,13 @@ def lut_forward_report():
             r = bg.bench(m, n, M)
             gemm.append({k: r[k] for k in ("out_x_in", "M", "lut_gemm_us", "lib_fp16_gemm_us", "dequant_plus_lib_us", "lut_gemm_TFLOPs",
                                            "lib_TFLOPs", "vs_lib", "vs_dequant_plus_lib")})
+    floor_us = bl.launch_floor()
+    for r in rows:  # the share of a call that is the harness's launch floor, and the rate over the rest
+        r["GBs_above_launch_floor"] = round(r["m"] * r["n"] * r["bits"] / 8 / max(r["lut_us"] - floor_us, 1e-3) / 1e3, 1)
     return {"gemm": gemm, "what": "y = x @ dequant(qweight, lut)^T, 4-bit, fp16 activations; device us per call from HIP-graph replays of 200 calls; "
-                    "cold = a ring of layers larger than the 256 MB Infinity Cache", "peak_GBs": HBM_PEAK_GBS, "shapes": rows,
+                    "cold = a ring of layers larger than the 256 MB Infinity Cache", "peak_GBs": HBM_PEAK_GBS,
+            "launch_floor_us": floor_us, "launch_floor_what": "a 1 KB fill kernel, 200 dependent launches in the same HIP graph: what any kernel costs here",
+            "shapes": rows,
             "llama32_1b_decoder_layer_M1_cold": {"linears": 7, "lut_us": round(lut_us, 2), "torch_fp16_us": round(f16_us, 2),
                                                  "speedup": round(f16_us / lut_us, 2)}}
 

@@ -34,6 +34,13 @@ def timed(fn, n_layers, iters):
     return s.elapsed_time(e) / (3 * iters) * 1e3  # us
 
 
+def launch_floor():
+    """what ANY kernel costs in this harness: a 256-thread fill of 1 KB, 200 dependent launches in the same HIP graph -- the time from
+    one kernel's start to the next one's start when nothing is computed (dispatch, completion signal, the barrier between the nodes)"""
+    t = torch.zeros(256, device="cuda")
+    return round(timed(lambda i: t.fill_(1.0), 1, 200), 2)
+
+
 def bench(m, n, bits, M, cold, outliers=0.0):
     V = 2 ** bits
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -81,6 +88,7 @@ if __name__ == "__main__":
                 print("ks", ks, bench(m, n, 4, M, True))
         sys.exit(0)
     rows = []
+    print({"launch_floor_us": launch_floor()})
     for (m, n) in [(4096, 4096), (14336, 4096), (4096, 14336), (2048, 2048), (8192, 2048), (2048, 8192)]:
         for M in (1, 16):
             for cold in (False, True):
