@@ -198,13 +198,16 @@ static int run_layer_impl(const float* W, const float* H, const float* L, int64_
         if (rc) return rc;
         if (k == 0 && ps) GANQ_HIP_CHECK(hipStreamWaitEvent(stream, ps->join, 0));
         // new codebook and, from the same A and b, the loss of (new codebook, these indices)  (ganq.py:589-591, :621-622)
-        rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, Tn, nullptr, nullptr, 1, nullptr, k, stream);
+        // from the second iteration on only the rows that changed are re-solved, in place in the current codebooks (the others are
+        // fixed points); the list doubles as the next S-solve's
+        const bool in_place = k >= 1 && t_rows_listable(lo.t);
+        rc = t_iterate(Qwork, m, n, V, rcond, lo.t, ws + lo.off_upd, nullptr, in_place ? Tc : Tn, nullptr, nullptr, 1, nullptr, k, stream, in_place);
         if (rc) return rc;
         if (k >= 1 && k + 1 < K) {
-            rc = t_active_rows(m, lo.t, ws + lo.off_upd, &rowlist, &nactive, stream);
+            rc = t_active_rows(m, lo.t, ws + lo.off_upd, &rowlist, &nactive, stream, in_place);
             if (rc) return rc;
         }
-        std::swap(Tc, Tn);
+        if (!in_place) std::swap(Tc, Tn);
         // per-iteration records for a caller that takes the best-of-K decision itself (row-sharded layers, tests)
         if (T_all)
             GANQ_HIP_CHECK(hipMemcpyAsync(T_all + (size_t)k * m * V, Tc, (size_t)m * V * sizeof(float), hipMemcpyDeviceToDevice, stream));

@@ -31,11 +31,17 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
 // calls; iter == 0 accumulates them in full, later calls only move the H entries of the indices that changed
 // (exact: the sums are integers), falling back to the full accumulation on the device when too many changed.
 int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
-              float* T_out, float* A_out, float* b_out, int loss_mode, double* loss_out, int iter, hipStream_t stream);
+              float* T_out, float* A_out, float* b_out, int loss_mode, double* loss_out, int iter, hipStream_t stream,
+              bool changed_rows_only = false);
+// changed_rows_only (iter >= 1): T_out holds the PREVIOUS codebooks and only the rows whose indices changed in this iteration are
+// solved and overwritten (the others are fixed points: same sums, same codebook, same loss); whether the layout / the test switches
+// allow that:
+bool t_rows_listable(const TLayout& lo);
 
 // after t_iterate(iter >= 1): rows whose indices changed in that iteration (device list + count; both null when
 // there are no change lists).  Unchanged rows are fixed points of the alternation and need no further S-solve.
-int t_active_rows(int64_t m, const TLayout& lo, char* ws, const int** list, const int** count, hipStream_t stream);
+int t_active_rows(int64_t m, const TLayout& lo, char* ws, const int** list, const int** count, hipStream_t stream,
+                  bool already_built = false);  // already_built: t_iterate(changed_rows_only) of this iteration made the list
 
 inline const double* t_loss_rows(const TLayout& lo, const char* ws) { return reinterpret_cast<const double*>(ws + lo.off_lossrows); }
 

@@ -890,7 +890,8 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
                                                      int n, int V, double rcond, float* __restrict__ T_out,
                                                      float* __restrict__ A_out, float* __restrict__ b_out,
                                                      double* __restrict__ loss_rows, int nparts,
-                                                     long long* __restrict__ changed_reset, int allow_fast) {
+                                                     long long* __restrict__ changed_reset, int allow_fast,
+                                                     const int* __restrict__ rowlist, const int* __restrict__ nrows) {
     // the change counter of this iteration has been consumed by the kernels in front of this one: leave it zero for
     // the next iteration's q_diff_kernel (saves a memset launch per iteration)
     if (changed_reset && blockIdx.x == 0 && threadIdx.x == 0) *changed_reset = 0;
@@ -905,7 +906,16 @@ __global__ __launch_bounds__(64) void t_solve_kernel(const long long* __restrict
 
     const int lane = threadIdx.x & 63;
     const int rs = lane >> 4, l = lane & 15;
-    const int row = blockIdx.x * 4 + rs;
+    // rowlist (iterations >= 1 of the fused loop): only the rows whose indices changed in this iteration are solved -- an unchanged row has
+    // the same bucket sums and the same b, hence the same codebook and loss, which stay where they are (T_out is then the previous
+    // codebook array, updated in place).  The row's work is dominated by streaming its 32 KB of W H, so the kernel's time follows
+    // the number of listed rows.
+    int row = blockIdx.x * 4 + rs;
+    if (rowlist) {
+        const int cnt = *nrows;
+        if ((int)blockIdx.x * 4 >= cnt) return;  // (uniform; behind the counter reset above)
+        row = row < cnt ? rowlist[row] : m;      // surplus row slots of the last workgroup: compute a valid row, store nothing
+    }
     const int rowc = min(row, m - 1);
     double(*A)[JS] = As[rs];
     double(*E)[JS] = Es[rs];
@@ -1435,7 +1445,7 @@ int t_prepare(const float* W, const float* H, int64_t m, int64_t n, const TLayou
 
 // per iteration: bucket sums (full: masks -> integer accumulation; or incremental) -> per-row solve (+ loss rows)
 int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const TLayout& lo, char* ws, const float* WH32,
-              float* T_out, float* A_out, float* b_out, int loss_mode, double* loss_out, int iter, hipStream_t stream) {
+              float* T_out, float* A_out, float* b_out, int loss_mode, double* loss_out, int iter, hipStream_t stream, bool changed_rows_only) {
     TPrep* prep = reinterpret_cast<TPrep*>(ws + lo.off_prep);
     int8_t* planes = reinterpret_cast<int8_t*>(ws + lo.off_planes);
     int* hdiag = reinterpret_cast<int*>(ws + lo.off_hdiag);
@@ -1519,6 +1529,17 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         }
     }
     GANQ_LAUNCH_CHECK();
+    // changed_rows_only (the fused loop, iterations >= 1, T_out = the previous codebooks): the per-row solve runs on the rows that
+    // changed in this iteration only; the list is the one the next S-solve takes as well (t_active_rows hands it out without a
+    // second launch)
+    const int* rowlist = nullptr;
+    const int* rowcount = nullptr;
+    if (changed_rows_only && stateful && iter >= 1 && t_rows_listable(lo)) {
+        int* l = reinterpret_cast<int*>(ws + lo.off_active);
+        hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, stream, chgcnt, (int)m, l, l + m);
+        rowlist = l;
+        rowcount = l + m;
+    }
     {
         ProfScope prof(KID_T_SOLVE, stream);
         const dim3 grid((unsigned)((m + 3) / 4));
@@ -1529,13 +1550,14 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
         if (WH32) {
             hipLaunchKernelGGL(t_solve_kernel<float>, grid, dim3(64), 0, stream, msrc, msrc_lo, prep, hdiag, hdiag_j, WH32,
                                static_cast<const double*>(nullptr), Q, (int)m, (int)n, V, rcond, T_out, A_out, b_out,
-                               static_cast<double*>(nullptr), nparts, static_cast<long long*>(nullptr), allow_fast);
+                               static_cast<double*>(nullptr), nparts, static_cast<long long*>(nullptr), allow_fast,
+                               static_cast<const int*>(nullptr), static_cast<const int*>(nullptr));
         } else {
             const double* WH64 = reinterpret_cast<const double*>(ws + lo.off_wh64);
             const double* wHw = reinterpret_cast<const double*>(ws + lo.off_whw);
             double* loss_rows = reinterpret_cast<double*>(ws + lo.off_lossrows);
             hipLaunchKernelGGL(t_solve_kernel<double>, grid, dim3(64), 0, stream, msrc, msrc_lo, prep, hdiag, hdiag_j, WH64, wHw, Q, (int)m,
-                               (int)n, V, rcond, T_out, A_out, b_out, loss_mode ? loss_rows : nullptr, nparts, changed, allow_fast);
+                               (int)n, V, rcond, T_out, A_out, b_out, loss_mode ? loss_rows : nullptr, nparts, changed, allow_fast, rowlist, rowcount);
             if (loss_mode == 2) hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, loss_rows, (int)m, loss_out);
         }
     }
@@ -1545,14 +1567,19 @@ int t_iterate(const uint8_t* Q, int64_t m, int64_t n, int V, double rcond, const
 
 // after t_iterate(iter >= 1): device list / count of the rows that changed in that iteration (null when the bucket sums
 // are not kept between iterations, i.e. no change lists exist)
-int t_active_rows(int64_t m, const TLayout& lo, char* ws, const int** list, const int** count, hipStream_t stream) {
+bool t_rows_listable(const TLayout& lo) {
+    // GANQ_SOLVE_ALL_ROWS=1 (test switch): never skip a row; GANQ_T_FULL=1: no change lists exist
+    return lo.off_hint != 0 && lo.off_active != 0 && opt_get(OPT_T_FULL) != 1 && opt_get(OPT_SOLVE_ALL_ROWS) != 1;
+}
+
+int t_active_rows(int64_t m, const TLayout& lo, char* ws, const int** list, const int** count, hipStream_t stream, bool already_built) {
     *list = nullptr;
     *count = nullptr;
-    // GANQ_SOLVE_ALL_ROWS=1 (test switch): never skip a row in the S-solve
-    if (lo.off_hint == 0 || lo.off_active == 0 || opt_get(OPT_T_FULL) == 1 || opt_get(OPT_SOLVE_ALL_ROWS) == 1) return 0;
+    if (!t_rows_listable(lo)) return 0;
     int* l = reinterpret_cast<int*>(ws + lo.off_active);
     int* c = l + m;
-    hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const int*>(ws + lo.off_chgcnt), (int)m, l, c);
+    if (!already_built)
+        hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const int*>(ws + lo.off_chgcnt), (int)m, l, c);
     GANQ_LAUNCH_CHECK();
     *list = l;
     *count = c;
@@ -1610,5 +1637,5 @@ extern "C" int ganq_update_t(const float* WH, const float* H, const uint8_t* Q, 
     char* ws = static_cast<char*>(workspace);
     int rc = t_prepare(nullptr, H, m, n, lo, ws, false, stream);
     if (rc) return rc;
-    return t_iterate(Q, m, n, V, rcond, lo, ws, WH, T_out, A_out, b_out, 0, nullptr, -1, stream);
+    return t_iterate(Q, m, n, V, rcond, lo, ws, WH, T_out, A_out, b_out, 0, nullptr, -1, stream, false);
 }
