@@ -730,7 +730,9 @@ __device__ __forceinline__ void mu_group(const int8_t* __restrict__ planes, int 
             for (int p = 0; p < NPL; ++p) bf[t][p] = *reinterpret_cast<const v4i*>(bp[t] + p * plane + k0);
     };
     // every step is one dependent round trip to L2 / Infinity Cache: D steps of operands are kept in flight
-    constexpr int D = NT == 1 ? 4 : 2;
+    // (with the extension's six planes half as many: the kernel then fits 168 registers -- three workgroups per CU instead of two for
+    // a kernel that is a chain of round trips per row; the six-plane path is the rare one)
+    constexpr int D = NPL == 6 ? (NT == 1 ? 2 : 1) : (NT == 1 ? 4 : 2);
     uint4 cw[D];
     v4i bf[D][NT][NPL];
     auto step = [&](const uint4& c, const v4i (&b)[NT][NPL]) {
@@ -757,7 +759,7 @@ __device__ __forceinline__ void mu_group(const int8_t* __restrict__ planes, int 
 
 // With the extension word on (prep->ext, uniform) the two extra digit planes ride along in the same pass and move the
 // second set of sums Mstate_lo; the pair / diagonal corrections come from Jint / hdiag_j.
-__global__ __launch_bounds__(MG_WAVES * 64) void m_update_mfma_kernel(const int8_t* __restrict__ planes, const int* __restrict__ Hint,
+__global__ __launch_bounds__(MG_WAVES * 64, 3) void m_update_mfma_kernel(const int8_t* __restrict__ planes, const int* __restrict__ Hint,
                                                            const short* __restrict__ Jint,
                                                            const int* __restrict__ hdiag_int, const int* __restrict__ hdiag_j,
                                                            const uint8_t* __restrict__ Q,
